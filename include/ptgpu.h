@@ -1,0 +1,185 @@
+/*
+ * ptgpu.h — C ABI of libptgpu, the MI355X (gfx950) path-tracing hot path.
+ *
+ * Drop-in boundary for jackdbd/path-tracer's renderer seam.  The reference has no
+ * FFI; the seam is the Zig function pair
+ *     render(cfg: Config) !void                  src/renderers/ppm_image.zig:30
+ *     renderMultiThread(ctx: ThreadContext) !void src/renderers/ppm_image.zig:91
+ * fed by Scene (src/scene.zig:19), Camera (src/camera.zig:18), Image
+ * (src/render_targets/ppm_image.zig:28) and RayTracerConfig (src/raytracer.zig:17).
+ * Zig structs / tagged unions have no defined layout, so what crosses here are the
+ * `extern struct`-compatible PODs below (all little-endian, natural alignment).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer it passes,
+ *     the library owns every device buffer it allocates (freed by ptgpu_destroy);
+ *   - every entry point returns an int status: PT_OK (0) or a negative PT_ERR_*;
+ *   - one context drives one GPU; a context is not re-entrant (one host thread at a
+ *     time per context); multi-GPU = one process (or context) per GPU, see
+ *     INTEGRATION.md;
+ *   - there is NO CPU fallback: without a usable gfx950 device ptgpu_create fails.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+    PT_OK = 0,
+    PT_ERR_BAD_ARG = -1,            /* null pointer, empty range, size mismatch      */
+    PT_ERR_NO_DEVICE = -2,          /* no HIP device / wrong architecture            */
+    PT_ERR_HIP = -3,                /* a HIP runtime call failed (ptgpu_last_hip)    */
+    PT_ERR_OOM = -4,                /* device allocation failed (Zig: OutOfMemory)   */
+    PT_ERR_DIRECTION_NOT_UNIT = -5, /* illumination.zig:29-31 DirectionIsNotUnitVector */
+    PT_ERR_VALUE_EXCEEDS_MAX = -6,  /* utils.zig:63-65 ValueExceedsMaxValue          */
+    PT_ERR_SCENE_NOT_AVAILABLE = -7,/* errors.zig:2  UserError.SceneNotAvailable     */
+    PT_ERR_NO_SPACE = -8,           /* caller buffer too small (Zig: NoSpaceLeft)    */
+    PT_ERR_UNSUPPORTED = -9         /* e.g. max_px_value != 255                      */
+};
+
+/* ---- material kinds: the tags of material.zig:174-178 ------------------- */
+enum { PT_LAMBERTIAN = 0, PT_METAL = 1, PT_DIELECTRIC = 2 };
+
+/* One Sphere (sphere.zig:36-40) with its Material union (material.zig:174-189)
+ * flattened: param = fuzziness for PT_METAL, refraction_index for PT_DIELECTRIC;
+ * albedo is ignored for PT_DIELECTRIC (attenuation is (1,1,1), material.zig:135).
+ * radius may be negative (scene.zig:48).  36 bytes. */
+typedef struct pt_sphere {
+    float cx, cy, cz;
+    float radius;
+    uint32_t kind;
+    float ar, ag, ab;
+    float param;
+} pt_sphere;
+
+/* The Camera fields castRay reads (camera.zig:99-106; built by Camera.new,
+ * camera.zig:48-97).  76 bytes. */
+typedef struct pt_camera {
+    float lookfrom[3];
+    float u[3];
+    float v[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float lens_radius;
+} pt_camera;
+
+/* RayTracerConfig (raytracer.zig:17-23) + the Image fields render() reads
+ * (renderers/ppm_image.zig:30-87) + the work range.  The reference's u8 counters
+ * are widened to u32 (BASELINE configs need up to 4096 paths per pixel).
+ *
+ * Samples of a pixel are numbered s = sample*rays_per_subsample + rps in the
+ * reference's loop order (renderers/ppm_image.zig:57-59), S = subpixels *
+ * rays_per_subsample in total.  [sample_start, sample_stop) selects a sub-range
+ * (sample-range split across GPUs); both 0 = all S samples.
+ * `chunk` = samples per work item; each work item's samples are summed in order
+ * and the partial sums of a pixel are then added in chunk order.  chunk = 0 (or
+ * >= the range) reproduces the reference's single sequential sum exactly.
+ * mode 1 = deterministic: every random draw returns 0.5 (pixel-centre rays, zero
+ * lens offset, scatter vector (0.5,0.5,0.5), dielectric xi = 0.5). */
+typedef struct pt_config {
+    uint32_t width, height;                 /* Image.width/.height                  */
+    uint32_t subpixels, rays_per_subsample; /* raytracer.zig:18,22                  */
+    uint32_t rebounds;                      /* raytracer.zig:21                     */
+    uint32_t mode;                          /* 0 stochastic (Philox), 1 deterministic */
+    uint64_t seed;                          /* Philox key                           */
+    float t_min, t_max;                     /* raytracer.zig:19-20; main.zig:87-88  */
+    float blend_start[3], blend_stop[3];    /* render_targets/ppm_image.zig:69-70   */
+    uint32_t idx_start, idx_stop;           /* renderers/ppm_image.zig:20-21 istart/istop */
+    uint32_t sample_start, sample_stop;
+    uint32_t chunk;
+    uint32_t max_px_value;                  /* Image.max_px_value (255)             */
+} pt_config;
+
+/* Counters of the last render on a context. */
+typedef struct pt_stats {
+    uint64_t paths;        /* camera samples traced                                  */
+    uint64_t rays;         /* ray segments = closest-hit queries (Scene.is_hit calls)*/
+    uint64_t sphere_tests; /* rays * n_spheres (what the reference's scan performs)  */
+    uint64_t candidates;   /* exact Sphere.is_hit evaluations after the LDS filter   */
+    uint64_t not_unit;     /* lerp() directions failing illumination.zig:29          */
+    double kernel_ms;      /* HIP-event time of the path-tracing kernel              */
+    double total_ms;       /* kernel + resolve (+ copies for host-pointer variants)  */
+} pt_stats;
+
+typedef struct ptgpu_ctx ptgpu_ctx;
+
+/* Create / destroy a context on HIP device `device` (replaces the thread set-up of
+ * main.zig:142-161).  Fails with PT_ERR_NO_DEVICE when there is no gfx950 GPU. */
+int ptgpu_create(int device, ptgpu_ctx **out);
+int ptgpu_destroy(ptgpu_ctx *ctx);
+
+/* Upload the scene (replaces passing *Scene, renderers/ppm_image.zig:25).  Builds
+ * the LDS-tile filter table and the exact sphere/material tables on the device. */
+int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_t n);
+
+/* Upload the camera (replaces passing *Camera, renderers/ppm_image.zig:18). */
+int ptgpu_set_camera(ptgpu_ctx *ctx, const pt_camera *cam);
+
+/* Radiance sums: for every pixel idx in [idx_start, idx_stop) the sum over the
+ * selected samples of illumination.radiance (illumination.zig:76) of
+ * camera.castRay (camera.zig:99) — the inner loops of render(),
+ * renderers/ppm_image.zig:49-69.  Output: width*height*3 floats (row-major, RGB);
+ * pixels outside the range are left untouched.
+ *   _device: d_rgb_sum is device memory; work is enqueued on `stream`
+ *            (a hipStream_t, NULL = default stream) and the call returns after the
+ *            kernels are enqueued and the stream is synchronised.
+ *   _host:   h_rgb_sum is host memory. */
+int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream);
+int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum);
+
+/* The resolve of renderers/ppm_image.zig:70-82 on the device: mean =
+ * sum*(1/subpixels)*(1/rays_per_subsample), *max_px_value, truncating u8, the
+ * 12-byte "%3d %3d %3d\n" record of render_targets/ppm_image.zig:93-103.
+ * d_records receives (idx_stop-idx_start)*12 bytes (record of pixel idx at
+ * (idx-idx_start)*12); either output may be NULL.  d_rgb8 receives 3 bytes/pixel. */
+int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const float *d_rgb_sum,
+                         uint8_t *d_records, uint8_t *d_rgb8, void *stream);
+
+/* Whole render() replacement on host buffers: traces [idx_start, idx_stop) and
+ * writes the pixel records into slice[header_size + idx*px_size ..], exactly the
+ * bytes render() writes (renderers/ppm_image.zig:81-82).  The caller writes the
+ * header afterwards (main.zig:180-182).  px_size must be 12 (max_px_value 255). */
+int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *slice, size_t slice_len,
+                     uint32_t header_size, uint32_t px_size);
+
+/* Mean radiance (after the two reciprocal multiplies of renderers/ppm_image.zig:70)
+ * as width*height*3 floats on the host; pixels outside the range untouched. */
+int ptgpu_render_mean_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_mean);
+
+/* Per-function device evaluation, used by the parity tests to pin each device
+ * function against the oracle on arrays of inputs.
+ * `fn` selects the function (PT_FN_*); `in`/`out` are host float arrays with
+ * `n` records of the per-function strides given beside each id (xi = the uniform
+ * draws the function consumes, in order; n_used = how many it consumed). */
+enum {
+    PT_FN_CAST_RAY = 0,    /* camera.zig:99     in: s,t,xi[16] (18)               out: o,d,n_used (7)      */
+    PT_FN_SPHERE_HIT = 1,  /* sphere.zig:63     in: o,d,c,r,tmin,tmax (12)        out: hit,t,p,n (8)       */
+    PT_FN_SCENE_HIT = 2,   /* scene.zig:96      in: o,d (6) (uses the ctx scene)  out: id,t,p,n (8)        */
+    PT_FN_SCATTER = 3,     /* material.zig:191  in: d,p,n,kind,param,xi[16] (27)  out: scattered d,n_used (4) */
+    PT_FN_REFRACT = 4,     /* material.zig:98   in: d,n,eta (7)                   out: ok,r (4)            */
+    PT_FN_SCHLICK = 5,     /* material.zig:120  in: cos,ri (2)                    out: prob (1)            */
+    PT_FN_REFLECT = 6,     /* material.zig:59   in: d,n (6)                       out: r (3)               */
+    PT_FN_LERP = 7,        /* illumination.zig:27 in: d,p0,p1 (9)                 out: err,rgb (4)         */
+    PT_FN_PHILOX = 8       /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
+};
+int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
+                     float t_min, float t_max);
+
+/* Diagnostics. */
+int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
+const char *ptgpu_strerror(int status);
+int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */
+int ptgpu_device_info(const ptgpu_ctx *ctx, int *compute_units, int *clock_khz, char *arch, size_t arch_len);
+uint32_t ptgpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libptgpu.so (include/ptgpu.h) — the C-ABI drop-in boundary.
+
+The library is built in-tree by path_tracer_amd/csrc/build.sh (hipcc, gfx950).  There is
+no fallback of any kind: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+
+PT_OK = 0
+PT_ERR_BAD_ARG = -1
+PT_ERR_NO_DEVICE = -2
+PT_ERR_HIP = -3
+PT_ERR_OOM = -4
+PT_ERR_DIRECTION_NOT_UNIT = -5
+PT_ERR_VALUE_EXCEEDS_MAX = -6
+PT_ERR_SCENE_NOT_AVAILABLE = -7
+PT_ERR_NO_SPACE = -8
+PT_ERR_UNSUPPORTED = -9
+
+PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
+
+(PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
+ PT_FN_LERP, PT_FN_PHILOX) = range(9)
+FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
+    PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
+    PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4)}
+
+# pt_sphere: 36 bytes
+SPHERE_DTYPE = np.dtype(
+    [("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4"), ("kind", "<u4"),
+     ("ar", "<f4"), ("ag", "<f4"), ("ab", "<f4"), ("param", "<f4")])
+assert SPHERE_DTYPE.itemsize == 36
+
+
+class pt_camera(C.Structure):
+    _fields_ = [("lookfrom", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3),
+                ("lower_left_corner", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("lens_radius", C.c_float)]
+
+
+class pt_config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("subpixels", C.c_uint32),
+                ("rays_per_subsample", C.c_uint32), ("rebounds", C.c_uint32), ("mode", C.c_uint32),
+                ("seed", C.c_uint64), ("t_min", C.c_float), ("t_max", C.c_float),
+                ("blend_start", C.c_float * 3), ("blend_stop", C.c_float * 3),
+                ("idx_start", C.c_uint32), ("idx_stop", C.c_uint32),
+                ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
+                ("chunk", C.c_uint32), ("max_px_value", C.c_uint32)]
+
+
+class pt_stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 88
+
+# every symbol include/ptgpu.h declares
+EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
+           "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
+           "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
+           "ptgpu_abi_version"]
+
+
+class PtGpuError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = strerror(status) if _lib is not None else str(status)
+        super().__init__("%s: %s (%d)" % (what, msg, status))
+
+
+_lib = None
+
+
+def load():
+    """dlopen libptgpu.so and declare its prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with path_tracer_amd/csrc/build.sh (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.ptgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ptgpu_destroy.argtypes = [vp]
+    L.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32]
+    L.ptgpu_set_camera.argtypes = [vp, C.POINTER(pt_camera)]
+    L.ptgpu_render_sum_device.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.ptgpu_render_sum_host.argtypes = [vp, C.POINTER(pt_config), vp]
+    L.ptgpu_render_mean_host.argtypes = [vp, C.POINTER(pt_config), vp]
+    L.ptgpu_resolve_device.argtypes = [vp, C.POINTER(pt_config), vp, vp, vp, vp]
+    L.ptgpu_render_ppm.argtypes = [vp, C.POINTER(pt_config), vp, C.c_size_t, C.c_uint32, C.c_uint32]
+    L.ptgpu_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_float, C.c_float]
+    L.ptgpu_get_stats.argtypes = [vp, C.POINTER(pt_stats)]
+    L.ptgpu_strerror.argtypes = [C.c_int]
+    L.ptgpu_strerror.restype = C.c_char_p
+    L.ptgpu_last_hip_error.argtypes = [vp]
+    L.ptgpu_device_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    L.ptgpu_abi_version.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def strerror(status):
+    return load().ptgpu_strerror(int(status)).decode()
+
+
+def check(status, what):
+    if status != PT_OK:
+        raise PtGpuError(status, what)

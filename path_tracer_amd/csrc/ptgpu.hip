@@ -1,0 +1,856 @@
+// ptgpu.hip — libptgpu: the MI355X (gfx950) path-tracing hot path behind the C ABI
+// of include/ptgpu.h.  Hand-written HIP for CDNA4 only (wave64, LDS tiles,
+// persistent workgroups); no CPU fallback.
+//
+// Kernel design (DESIGN.md has the long form):
+//   * one lane = one path; a persistent wave keeps all 64 lanes busy by refilling a
+//     lane's path as soon as it terminates (next sample of its work item, or a new
+//     work item from an atomic queue, fetched with one atomic per wave via
+//     ballot/popcount) — replaces the thread split of multithreading.zig;
+//   * Scene.is_hit (scene.zig:96-110) = a linear scan over a filter table
+//     (cx,cy,cz,threshold) staged into LDS in tiles: 7 FMAs + 1 compare per sphere
+//     decide conservatively whether the reference's discriminant can be >= 0; the
+//     few survivors are queued per lane (LDS) and evaluated afterwards with the
+//     reference's exact arithmetic (sphere.zig:63-103), in list order, so the
+//     closest hit is the reference's bit for bit;
+//   * radiance (illumination.zig:76-90) = iterative bounce loop; the hit sphere of
+//     every bounce is pushed on a per-lane stack in HBM and the attenuations are
+//     multiplied innermost-first when the path ends, as the recursion does.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/ptgpu.h"
+#include "pt_device.h"
+
+using namespace ptdev;
+
+#define PT_ABI_VERSION 1u
+
+// ---------------------------------------------------------------------------
+// kernel parameters
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kTile = 1024;          // spheres per LDS tile (16 KiB of float4)
+constexpr int kSub = 4;              // spheres per software-pipeline stage (one s_load_dwordx16)
+constexpr int kCandCap = 32;         // candidate slots per lane (u16 tile-relative ids, slot-major in LDS)
+constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
+
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_N = 8 };
+
+struct KParams {
+    Cam cam;
+    V3 blend_start, blend_stop;
+    float t_min, t_max;
+    uint32_t width, height;
+    uint32_t rebounds;
+    uint32_t seed_lo, seed_hi;
+    uint32_t idx_start, npix;       // pixel range [idx_start, idx_start + npix)
+    uint32_t s0, s1, chunk, nchunks; // sample range and chunking
+    uint32_t nspheres;
+    uint32_t total_threads;
+    const float4 *filt; // (cx, cy, cz, threshold) padded to a multiple of 2*kSub
+    const float4 *geom; // (cx, cy, cz, radius)
+    const float4 *mat;  // (albedo r, g, b, param)
+    const uint32_t *kind;
+    float *part;        // [nchunks][npix][3] partial sums
+    uint32_t *stack;    // [rebounds][total_threads] hit ids
+    unsigned long long *counters;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// the megakernel
+// ---------------------------------------------------------------------------
+// FEED selects how the wave-uniform filter records reach the VALU:
+//   FEED_SGPR      scalar loads (s_load_dwordx16 = 4 records) through the scalar cache
+//                  into SGPRs, used directly as VALU operands: no VGPRs, no LDS reads;
+//   FEED_LDS       the whole table staged once into an LDS tile, broadcast ds_read_b128;
+//   FEED_LDS_TILES tables larger than one tile: tiles restaged per ray step (block-wide).
+enum { FEED_SGPR = 0, FEED_LDS = 1, FEED_LDS_TILES = 2 };
+
+typedef __attribute__((address_space(4))) const float4 cfloat4; // constant address space: scalar loads
+
+template <bool DET, int FEED>
+__global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
+    constexpr bool MULTI_TILE = (FEED == FEED_LDS_TILES);
+    constexpr uint32_t TILE = (FEED == FEED_SGPR) ? 32768u : (uint32_t)kTile; // u16 tile-relative ids
+    __shared__ float4 s_filt[(FEED == FEED_SGPR) ? 1 : kTile];
+    __shared__ uint16_t s_cand[kCandCap * kBlock];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t gtid = blockIdx.x * kBlock + tid;
+
+    const uint32_t n_pad = (P.nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    if (FEED == FEED_LDS) {
+        for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
+        __syncthreads();
+    }
+
+    // per-lane path state
+    bool alive = true;      // lane still has (or can get) work
+    bool need_path = true;  // lane needs a new camera sample
+    uint32_t pixel = 0, sample = 0, s_end = 0, out_slot = 0;
+    bool has_item = false;
+    V3 accum = v3(0.f, 0.f, 0.f);
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 1.f, 0.f);
+    uint32_t bounce = 0;
+    typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
+    rng.init(P.seed_lo, P.seed_hi);
+    unsigned long long n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0;
+    const uint32_t total_items = P.npix * P.nchunks;
+
+    for (;;) {
+        // ---- phase A: refill lanes whose path has ended -------------------------
+        if (alive && need_path && sample == s_end) {
+            if (has_item) {
+                float *dst = P.part + 3ull * out_slot;
+                dst[0] = accum.x; dst[1] = accum.y; dst[2] = accum.z;
+                has_item = false;
+            }
+        }
+        {
+            const bool want = alive && need_path && sample == s_end;
+            const unsigned long long m = __ballot(want);
+            if (m != 0ull) {
+                uint32_t base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if ((int)lane == leader)
+                    base = (uint32_t)atomicAdd(&P.counters[CNT_QUEUE], (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (want) {
+                    const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (item < total_items) {
+                        const uint32_t k = item / P.npix;
+                        const uint32_t po = item - k * P.npix;
+                        pixel = P.idx_start + po;
+                        sample = P.s0 + k * P.chunk;
+                        s_end = min(sample + P.chunk, P.s1);
+                        out_slot = item; // part[k][po]
+                        accum = v3(0.f, 0.f, 0.f);
+                        has_item = true;
+                        n_paths += s_end - sample;
+                    } else {
+                        alive = false;
+                        o = v3(0.f, 0.f, 0.f); d = v3(0.f, 1.f, 0.f);
+                    }
+                }
+            }
+        }
+        if (MULTI_TILE) {
+            if (!__syncthreads_or(alive ? 1 : 0)) break;
+        } else {
+            if (__ballot(alive) == 0ull) break;
+        }
+        if (alive && need_path) {
+            // renderers/ppm_image.zig:50-51,61-63
+            rng.start_path(pixel, sample);
+            const uint32_t i_col = pixel % P.width;
+            const uint32_t i_row = pixel / P.width;
+            const float u = ((float)i_col + rng.next()) / (float)P.width;
+            const float v = ((float)(P.height - i_row + 1u) + rng.next()) / (float)P.height;
+            cast_ray(P.cam, u, v, rng, o, d);
+            bounce = 0;
+            need_path = false;
+        }
+
+        // ---- phase B: Scene.is_hit (scene.zig:96-110) ---------------------------
+        // conservative filter over the LDS tile(s), exact test on the survivors
+        const float a = vlen2(d); // sphere.zig:68
+        float closest = P.t_max;
+        int hit = -1;
+        {
+            const float inv = rsqrtf(a);
+            const float hx = d.x * inv, hy = d.y * inv, hz = d.z * inv;
+            const float od = fmaf(o.z, hz, fmaf(o.y, hy, o.x * hx));
+            const float oo = fmaf(o.z, o.z, fmaf(o.y, o.y, o.x * o.x));
+            const float wx = 2.0f * fmaf(-od, hx, o.x);
+            const float wy = 2.0f * fmaf(-od, hy, o.y);
+            const float wz = 2.0f * fmaf(-od, hz, o.z);
+            const float E = fmaf(od, od, (kKeps - 1.0f) * oo);
+            uint32_t cnt = 0;
+
+            auto flush = [&](uint32_t tile_base) {
+                // exact Sphere.is_hit on this lane's queued candidates, in list order
+                n_cands += cnt;
+                for (uint32_t i = 0; __ballot(i < cnt) != 0ull; ++i) {
+                    if (i < cnt) {
+                        const uint32_t j = tile_base + s_cand[i * kBlock + tid];
+                        const float4 g = P.geom[j];
+                        float t;
+                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
+                            if (t < closest) { closest = t; hit = (int)j; }
+                        }
+                    }
+                }
+                cnt = 0;
+            };
+
+            const cfloat4 *filt_c = (const cfloat4 *)(P.filt);
+            for (uint32_t tile = 0; tile < n_pad; tile += TILE) {
+                const uint32_t tn = min(TILE, n_pad - tile);
+                if (MULTI_TILE) {
+                    __syncthreads();
+                    for (uint32_t i = tid; i < tn; i += kBlock) s_filt[i] = P.filt[tile + i];
+                    __syncthreads();
+                }
+                // Software-pipelined scan: the filter records of the next kSub spheres
+                // are fetched while the current kSub are tested; two register sets,
+                // ping-pong, no copies.
+                auto load = [&](float4 (&f)[kSub], uint32_t j0) {
+#pragma unroll
+                    for (int k = 0; k < kSub; ++k) {
+                        if (FEED == FEED_SGPR) {
+                            const cfloat4 *src = filt_c + (tile + j0 + k);
+                            f[k].x = src->x; f[k].y = src->y; f[k].z = src->z; f[k].w = src->w;
+                        } else {
+                            f[k] = s_filt[j0 + k];
+                        }
+                    }
+                };
+                auto test = [&](const float4 (&f)[kSub], uint32_t j0) {
+                    if (__ballot(cnt > (uint32_t)(kCandCap - kSub)) != 0ull) flush(tile);
+#pragma unroll
+                    for (int k = 0; k < kSub; ++k) {
+                        float q = f[k].x * hx;
+                        q = fmaf(f[k].y, hy, q);
+                        q = fmaf(f[k].z, hz, q);
+                        float s = fmaf(f[k].x, wx, E);
+                        s = fmaf(f[k].y, wy, s);
+                        s = fmaf(f[k].z, wz, s);
+                        const float F = fmaf(q, q, s);
+                        if (F >= f[k].w) {
+                            s_cand[cnt * kBlock + tid] = (uint16_t)(j0 + k);
+                            cnt++;
+                        }
+                    }
+                };
+                float4 fa[kSub], fb[kSub];
+                load(fa, 0);
+                for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) { // n_pad is a multiple of 2*kSub
+                    load(fb, j0 + kSub);
+                    test(fa, j0);
+                    if (j0 + 2 * kSub < tn) load(fa, j0 + 2 * kSub);
+                    test(fb, j0 + kSub);
+                }
+                flush(tile); // ids are tile-relative: drain before moving on
+            }
+        }
+        if (alive) n_rays++;
+
+        // ---- phase C: radiance step (illumination.zig:76-90) ---------------------
+        if (alive) {
+            bool done = false;
+            V3 color = v3(0.f, 0.f, 0.f);
+            bool ok = true;
+            if (hit >= 0) {
+                if (bounce == P.rebounds) {
+                    done = true; // illumination.zig:80-81: black
+                } else {
+                    const float4 g = P.geom[hit];
+                    const float4 m = P.mat[hit];
+                    const uint32_t kind = P.kind[hit];
+                    V3 p, n;
+                    sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, n);
+                    const V3 nd = scatter(kind, m.w, d, p, n, rng);
+                    P.stack[(size_t)bounce * P.total_threads + gtid] = (uint32_t)hit;
+                    bounce++;
+                    o = p; d = nd;
+                }
+            } else {
+                ok = lerp_sky(d, P.blend_start, P.blend_stop, color); // illumination.zig:88
+                // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
+                for (uint32_t b = bounce; b > 0; --b) {
+                    const uint32_t id = P.stack[(size_t)(b - 1) * P.total_threads + gtid];
+                    if (P.kind[id] != 2u) {
+                        const float4 m = P.mat[id];
+                        color = vemul(color, v3(m.x, m.y, m.z));
+                    } else {
+                        color = vemul(color, v3(1.0f, 1.0f, 1.0f)); // material.zig:135
+                    }
+                }
+                done = true;
+            }
+            if (done) {
+                if (ok) accum = vadd(accum, color); // renderers/ppm_image.zig:67
+                else n_not_unit++;
+                sample++;
+                need_path = true;
+            }
+        }
+    }
+
+    // ---- statistics ---------------------------------------------------------------
+    n_rays = wave_sum_u64(n_rays);
+    n_cands = wave_sum_u64(n_cands);
+    n_paths = wave_sum_u64(n_paths);
+    n_not_unit = wave_sum_u64(n_not_unit);
+    if (lane == 0) {
+        atomicAdd(&P.counters[CNT_RAYS], n_rays);
+        atomicAdd(&P.counters[CNT_CANDS], n_cands);
+        atomicAdd(&P.counters[CNT_PATHS], n_paths);
+        if (n_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], n_not_unit);
+    }
+}
+
+// Sum the chunk partials of a pixel in chunk order: total = p0; total += p1; ...
+__global__ void pt_sum_chunks(const float *part, uint32_t npix, uint32_t nchunks, uint32_t idx_start, float *rgb_sum) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // over npix*3
+    if (i >= npix * 3u) return;
+    float total = part[i];
+    for (uint32_t k = 1; k < nchunks; ++k) total = total + part[(size_t)k * npix * 3u + i];
+    rgb_sum[(size_t)idx_start * 3u + i] = total;
+}
+
+// renderers/ppm_image.zig:70 — the two reciprocal multiplies
+__global__ void pt_mean(const float *rgb_sum, uint32_t idx_start, uint32_t npix, float k1, float k2, float *rgb_mean) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 3u) return;
+    const size_t at = (size_t)idx_start * 3u + i;
+    rgb_mean[at] = k2 * (k1 * rgb_sum[at]);
+}
+
+// "%3d" of utils.zig:62-84: left-padded to three characters
+__device__ __forceinline__ void put3(uint8_t *dst, uint32_t v) {
+    const uint32_t h = v / 100u, t = (v / 10u) % 10u, u = v % 10u;
+    dst[0] = (v >= 100u) ? (uint8_t)('0' + h) : (uint8_t)' ';
+    dst[1] = (v >= 10u) ? (uint8_t)('0' + t) : (uint8_t)' ';
+    dst[2] = (uint8_t)('0' + u);
+}
+
+// renderers/ppm_image.zig:70-82 + render_targets/ppm_image.zig:93-103
+__global__ void pt_resolve(const float *rgb_sum, uint32_t idx_start, uint32_t npix, float k1, float k2, float max_val_f,
+                           uint8_t *records, uint8_t *rgb8, unsigned long long *counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const size_t at = ((size_t)idx_start + i) * 3u;
+    uint32_t q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float mean = k2 * (k1 * rgb_sum[at + c]);
+        const float col = max_val_f * mean;
+        // @floatToInt(u8, col): truncation; out of range is undefined in the
+        // reference's ReleaseFast build — clamped here and counted.
+        uint32_t v;
+        if (!(col > 0.0f)) v = 0u;
+        else if (col >= 256.0f) { v = 255u; atomicAdd(&counters[CNT_N - 1], 1ull); }
+        else v = (uint32_t)col;
+        if (v > 255u) v = 255u;
+        q[c] = v;
+    }
+    if (rgb8) { rgb8[(size_t)i * 3u] = (uint8_t)q[0]; rgb8[(size_t)i * 3u + 1] = (uint8_t)q[1]; rgb8[(size_t)i * 3u + 2] = (uint8_t)q[2]; }
+    if (records) {
+        uint8_t rec[12];
+        put3(rec, q[0]); rec[3] = ' ';
+        put3(rec + 4, q[1]); rec[7] = ' ';
+        put3(rec + 8, q[2]); rec[11] = '\n';
+        uint32_t *dst = reinterpret_cast<uint32_t *>(records + (size_t)i * 12u);
+        dst[0] = (uint32_t)rec[0] | ((uint32_t)rec[1] << 8) | ((uint32_t)rec[2] << 16) | ((uint32_t)rec[3] << 24);
+        dst[1] = (uint32_t)rec[4] | ((uint32_t)rec[5] << 8) | ((uint32_t)rec[6] << 16) | ((uint32_t)rec[7] << 24);
+        dst[2] = (uint32_t)rec[8] | ((uint32_t)rec[9] << 8) | ((uint32_t)rec[10] << 16) | ((uint32_t)rec[11] << 24);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-function evaluation kernel (parity tests pin each device function)
+// ---------------------------------------------------------------------------
+__global__ void pt_debug_eval(int fn, const float *in, float *out, uint32_t n, Cam cam, const float4 *geom,
+                              const float4 *mat, const uint32_t *kind, uint32_t nspheres, float t_min, float t_max) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (fn) {
+    case PT_FN_SPHERE_HIT: {
+        const float *r = in + (size_t)i * 12; float *w = out + (size_t)i * 8;
+        const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+        float t = 0.f; V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+        const bool h = sphere_near_root(o, d, vlen2(d), r[6], r[7], r[8], r[9], r[10], r[11], t);
+        if (h) sphere_hit_point(o, d, t, r[6], r[7], r[8], r[9], p, nn);
+        w[0] = h ? 1.f : 0.f; w[1] = t; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
+        break;
+    }
+    case PT_FN_SCENE_HIT: { // plain exact scan (the reference's loop), no filter
+        const float *r = in + (size_t)i * 6; float *w = out + (size_t)i * 8;
+        const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+        const float a = vlen2(d);
+        float closest = t_max; int hit = -1;
+        for (uint32_t j = 0; j < nspheres; ++j) {
+            const float4 g = geom[j]; float t;
+            if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t) && t < closest) { closest = t; hit = (int)j; }
+        }
+        V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+        if (hit >= 0) { const float4 g = geom[hit]; sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, nn); }
+        w[0] = (float)hit; w[1] = (hit >= 0) ? closest : 0.f; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
+        break;
+    }
+    case PT_FN_REFRACT: {
+        const float *r = in + (size_t)i * 7; float *w = out + (size_t)i * 4;
+        V3 res = v3(0, 0, 0);
+        const bool ok = refract(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], res);
+        w[0] = ok ? 1.f : 0.f; w[1] = res.x; w[2] = res.y; w[3] = res.z;
+        break;
+    }
+    case PT_FN_SCHLICK: out[i] = schlick(in[(size_t)i * 2], in[(size_t)i * 2 + 1]); break;
+    case PT_FN_REFLECT: {
+        const float *r = in + (size_t)i * 6;
+        const V3 res = reflect(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
+        out[(size_t)i * 3] = res.x; out[(size_t)i * 3 + 1] = res.y; out[(size_t)i * 3 + 2] = res.z;
+        break;
+    }
+    case PT_FN_LERP: {
+        const float *r = in + (size_t)i * 9; float *w = out + (size_t)i * 4;
+        V3 res = v3(0, 0, 0);
+        const bool ok = lerp_sky(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), v3(r[6], r[7], r[8]), res);
+        w[0] = ok ? 0.f : 1.f; w[1] = res.x; w[2] = res.y; w[3] = res.z;
+        break;
+    }
+    case PT_FN_PHILOX: {
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(in) + (size_t)i * 5;
+        uint32_t a, b, c, dd;
+        philox4x32_10(r[2], r[3], r[4], 0u, r[0], r[1], a, b, c, dd);
+        out[(size_t)i * 4] = u32_to_float(a); out[(size_t)i * 4 + 1] = u32_to_float(b);
+        out[(size_t)i * 4 + 2] = u32_to_float(c); out[(size_t)i * 4 + 3] = u32_to_float(dd);
+        break;
+    }
+    default: break;
+    }
+}
+
+// cast_ray and scatter consume random draws: the debug variants take the draws from
+// the input record (ArrayRng) so that the oracle can be fed the same numbers.
+__global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t n, Cam cam) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (fn == PT_FN_CAST_RAY) {
+        // in: s, t, xi[16] (18)   out: o, d, n_used (7)
+        const float *r = in + (size_t)i * 18; float *w = out + (size_t)i * 7;
+        ArrayRng ar{r + 2, 0u, 16u};
+        V3 origin, dir;
+        cast_ray(cam, r[0], r[1], ar, origin, dir);
+        w[0] = origin.x; w[1] = origin.y; w[2] = origin.z; w[3] = dir.x; w[4] = dir.y; w[5] = dir.z; w[6] = (float)ar.n;
+    } else if (fn == PT_FN_SCATTER) {
+        // in: d(3), p(3), n(3), kind, param, xi[16] (27)   out: scattered d (3), n_used (4)
+        const float *r = in + (size_t)i * 27; float *w = out + (size_t)i * 4;
+        ArrayRng ar{r + 11, 0u, 16u};
+        const V3 nd = scatter((uint32_t)r[9], r[10], v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), v3(r[6], r[7], r[8]), ar);
+        w[0] = nd.x; w[1] = nd.y; w[2] = nd.z; w[3] = (float)ar.n;
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// host side: context, uploads, launches
+// ---------------------------------------------------------------------------
+struct ptgpu_ctx {
+    int device = -1;
+    int compute_units = 0;
+    int clock_khz = 0;
+    char arch[64] = {0};
+    int last_hip = 0;
+    uint32_t nspheres = 0, n_pad = 0;
+    float4 *d_filt = nullptr, *d_geom = nullptr, *d_mat = nullptr;
+    uint32_t *d_kind = nullptr;
+    bool have_camera = false;
+    Cam cam;
+    float *d_part = nullptr; size_t part_bytes = 0;
+    uint32_t *d_stack = nullptr; size_t stack_bytes = 0;
+    float *d_tmp = nullptr; size_t tmp_bytes = 0;    // scratch image for host-pointer variants
+    uint8_t *d_rec = nullptr; size_t rec_bytes = 0;  // scratch records for ptgpu_render_ppm
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    int blocks_per_cu = 4;
+    int feed = 0; // FEED_SGPR; PTGPU_FEED=lds selects the LDS-tile variant (A/B measurement)
+    pt_stats stats;
+};
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) {                              \
+            (ctx)->last_hip = (int)e_;                       \
+            return (e_ == hipErrorOutOfMemory) ? PT_ERR_OOM : PT_ERR_HIP; \
+        }                                                    \
+    } while (0)
+
+static int ensure(ptgpu_ctx *ctx, void **ptr, size_t *have, size_t want) {
+    if (*have >= want && *ptr) return PT_OK;
+    if (*ptr) { HIP_TRY(ctx, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(ctx, hipMalloc(ptr, want));
+    *have = want;
+    return PT_OK;
+}
+
+extern "C" uint32_t ptgpu_abi_version(void) { return PT_ABI_VERSION; }
+
+extern "C" const char *ptgpu_strerror(int status) {
+    switch (status) {
+    case PT_OK: return "ok";
+    case PT_ERR_BAD_ARG: return "bad argument";
+    case PT_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+    case PT_ERR_HIP: return "HIP runtime error";
+    case PT_ERR_OOM: return "out of device memory";
+    case PT_ERR_DIRECTION_NOT_UNIT: return "DirectionIsNotUnitVector";
+    case PT_ERR_VALUE_EXCEEDS_MAX: return "ValueExceedsMaxValue";
+    case PT_ERR_SCENE_NOT_AVAILABLE: return "SceneNotAvailable";
+    case PT_ERR_NO_SPACE: return "NoSpaceLeft";
+    case PT_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
+    if (!out) return PT_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PT_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PT_ERR_NO_DEVICE; // built for gfx950 only
+    ptgpu_ctx *ctx = new (std::nothrow) ptgpu_ctx();
+    if (!ctx) return PT_ERR_OOM;
+    ctx->device = device;
+    ctx->compute_units = prop.multiProcessorCount;
+    ctx->clock_khz = prop.clockRate;
+    strncpy(ctx->arch, prop.gcnArchName, sizeof(ctx->arch) - 1);
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, CNT_N * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    if (e != hipSuccess) { delete ctx; return PT_ERR_HIP; }
+    const char *bpc = getenv("PTGPU_BLOCKS_PER_CU");
+    if (bpc && atoi(bpc) > 0 && atoi(bpc) <= 8) ctx->blocks_per_cu = atoi(bpc);
+    const char *feed = getenv("PTGPU_FEED");
+    if (feed && strcmp(feed, "lds") == 0) ctx->feed = 1;
+    *out = ctx;
+    return PT_OK;
+}
+
+extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    delete ctx;
+    return PT_OK;
+}
+
+extern "C" int ptgpu_device_info(const ptgpu_ctx *ctx, int *compute_units, int *clock_khz, char *arch, size_t arch_len) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (clock_khz) *clock_khz = ctx->clock_khz;
+    if (arch && arch_len) { strncpy(arch, ctx->arch, arch_len - 1); arch[arch_len - 1] = 0; }
+    return PT_OK;
+}
+
+extern "C" int ptgpu_last_hip_error(const ptgpu_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+extern "C" int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out) {
+    if (!ctx || !out) return PT_ERR_BAD_ARG;
+    *out = ctx->stats;
+    return PT_OK;
+}
+
+// The filter threshold of sphere j (see the kernel comment): with c the centre,
+// cc = |c|^2, r2 = radius^2 and M = |o|^2 + cc, the kernel evaluates
+//   F = (oc.dh)^2 - |oc|^2 + cc + Keps*|o|^2     (dh = d/|d|, oc = o - c)
+// and queues the sphere iff F >= cc - r2 - Keps*cc, i.e. iff
+//   (oc.dh)^2 - |oc|^2 + r2 + Keps*M >= 0.
+// The reference's float discriminant can only be >= 0 when the real-arithmetic one is
+// >= -~90*2^-24*M (rounding of both sides), Keps = 2^-16 = 256*2^-24.  Evaluated in
+// double and rounded toward -inf.
+static float filter_threshold(const pt_sphere &s) {
+    const double cx = s.cx, cy = s.cy, cz = s.cz, r = s.radius;
+    const double cc = cx * cx + cy * cy + cz * cz;
+    const double thr = cc - r * r - (double)kKeps * cc;
+    float f = (float)thr;
+    if ((double)f > thr) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_t n) {
+    if (!ctx || !spheres || n == 0) return PT_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; ++i)
+        if (spheres[i].kind > PT_DIELECTRIC) return PT_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_pad = (n + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    std::vector<float4> filt(n_pad), geom(n), mat(n);
+    std::vector<uint32_t> kind(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const pt_sphere &s = spheres[i];
+        filt[i] = make_float4(s.cx, s.cy, s.cz, filter_threshold(s));
+        geom[i] = make_float4(s.cx, s.cy, s.cz, s.radius);
+        mat[i] = make_float4(s.ar, s.ag, s.ab, s.param);
+        kind[i] = s.kind;
+    }
+    for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, 0.f, INFINITY); // never a candidate
+    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind};
+    for (void *p : olds) if (p) HIP_TRY(ctx, hipFree(p));
+    ctx->d_filt = ctx->d_geom = ctx->d_mat = nullptr; ctx->d_kind = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_filt, n_pad * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_geom, n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_mat, n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_kind, n * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_filt, filt.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_kind, kind.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->nspheres = n;
+    ctx->n_pad = n_pad;
+    return PT_OK;
+}
+
+static Cam to_cam(const pt_camera *c) {
+    Cam k;
+    k.lookfrom = v3(c->lookfrom[0], c->lookfrom[1], c->lookfrom[2]);
+    k.u = v3(c->u[0], c->u[1], c->u[2]);
+    k.v = v3(c->v[0], c->v[1], c->v[2]);
+    k.llc = v3(c->lower_left_corner[0], c->lower_left_corner[1], c->lower_left_corner[2]);
+    k.horizontal = v3(c->horizontal[0], c->horizontal[1], c->horizontal[2]);
+    k.vertical = v3(c->vertical[0], c->vertical[1], c->vertical[2]);
+    k.lens_radius = c->lens_radius;
+    return k;
+}
+
+extern "C" int ptgpu_set_camera(ptgpu_ctx *ctx, const pt_camera *cam) {
+    if (!ctx || !cam) return PT_ERR_BAD_ARG;
+    ctx->cam = to_cam(cam);
+    ctx->have_camera = true;
+    return PT_OK;
+}
+
+static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, uint32_t *s1, uint32_t *chunk) {
+    if (!ctx || !cfg) return PT_ERR_BAD_ARG;
+    if (!ctx->d_filt || !ctx->have_camera) return PT_ERR_BAD_ARG;
+    if (cfg->width == 0 || cfg->height == 0 || cfg->subpixels == 0 || cfg->rays_per_subsample == 0) return PT_ERR_BAD_ARG;
+    const uint64_t np = (uint64_t)cfg->width * cfg->height;
+    if (np > 0x7fffffffull / 3) return PT_ERR_BAD_ARG;
+    if (cfg->idx_start > cfg->idx_stop || cfg->idx_stop > np) return PT_ERR_BAD_ARG;
+    if (cfg->mode > 1) return PT_ERR_BAD_ARG;
+    const uint64_t S = (uint64_t)cfg->subpixels * cfg->rays_per_subsample;
+    if (S > 0xffffffffull) return PT_ERR_BAD_ARG;
+    uint32_t a = cfg->sample_start, b = cfg->sample_stop;
+    if (a == 0 && b == 0) b = (uint32_t)S;
+    if (a > b || b > S) return PT_ERR_BAD_ARG;
+    uint32_t c = cfg->chunk;
+    if (c == 0 || c > b - a) c = (b > a) ? b - a : 1;
+    *s0 = a; *s1 = b; *chunk = c;
+    return PT_OK;
+}
+
+extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream_) {
+    uint32_t s0, s1, chunk;
+    int rc = check_cfg(ctx, cfg, &s0, &s1, &chunk);
+    if (rc != PT_OK) return rc;
+    if (!d_rgb_sum) return PT_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    if (npix == 0 || s1 == s0) return PT_OK;
+    const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
+    if ((uint64_t)npix * nchunks > 0xfffffff0ull) return PT_ERR_BAD_ARG;
+
+    const uint32_t grid = (uint32_t)(ctx->compute_units * ctx->blocks_per_cu);
+    const uint32_t total_threads = grid * kBlock;
+
+    float *part = nullptr;
+    if (nchunks == 1) {
+        part = d_rgb_sum + (size_t)cfg->idx_start * 3u; // write sums in place
+    } else {
+        rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, (size_t)nchunks * npix * 3u * sizeof(float));
+        if (rc != PT_OK) return rc;
+        part = ctx->d_part;
+    }
+    const size_t stack_need = (size_t)(cfg->rebounds ? cfg->rebounds : 1u) * total_threads * sizeof(uint32_t);
+    rc = ensure(ctx, (void **)&ctx->d_stack, &ctx->stack_bytes, stack_need);
+    if (rc != PT_OK) return rc;
+
+    KParams P;
+    P.cam = ctx->cam;
+    P.blend_start = v3(cfg->blend_start[0], cfg->blend_start[1], cfg->blend_start[2]);
+    P.blend_stop = v3(cfg->blend_stop[0], cfg->blend_stop[1], cfg->blend_stop[2]);
+    P.t_min = cfg->t_min; P.t_max = cfg->t_max;
+    P.width = cfg->width; P.height = cfg->height;
+    P.rebounds = cfg->rebounds;
+    P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
+    P.idx_start = cfg->idx_start; P.npix = npix;
+    P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
+    P.nspheres = ctx->nspheres;
+    P.total_threads = total_threads;
+    P.filt = ctx->d_filt; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind;
+    P.part = part; P.stack = ctx->d_stack; P.counters = ctx->d_counters;
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    int feed = ctx->feed;
+    if (feed != FEED_SGPR) feed = (ctx->n_pad > (uint32_t)kTile) ? FEED_LDS_TILES : FEED_LDS;
+    const bool det = cfg->mode == 1;
+#define PT_LAUNCH(D, F) hipLaunchKernelGGL((pt_megakernel<D, F>), dim3(grid), dim3(kBlock), 0, stream, P)
+    if (det) {
+        if (feed == FEED_SGPR) PT_LAUNCH(true, FEED_SGPR);
+        else if (feed == FEED_LDS) PT_LAUNCH(true, FEED_LDS);
+        else PT_LAUNCH(true, FEED_LDS_TILES);
+    } else {
+        if (feed == FEED_SGPR) PT_LAUNCH(false, FEED_SGPR);
+        else if (feed == FEED_LDS) PT_LAUNCH(false, FEED_LDS);
+        else PT_LAUNCH(false, FEED_LDS_TILES);
+    }
+#undef PT_LAUNCH
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+    if (nchunks > 1) {
+        const uint32_t n3 = npix * 3u;
+        hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)part, npix, nchunks, cfg->idx_start, d_rgb_sum);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev2, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    unsigned long long h[CNT_N];
+    HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    float ms01 = 0.f, ms02 = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms01, ctx->ev0, ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms02, ctx->ev0, ctx->ev2));
+    ctx->stats.paths = h[CNT_PATHS];
+    ctx->stats.rays = h[CNT_RAYS];
+    ctx->stats.sphere_tests = h[CNT_RAYS] * ctx->nspheres;
+    ctx->stats.candidates = h[CNT_CANDS];
+    ctx->stats.not_unit = h[CNT_NOT_UNIT];
+    ctx->stats.kernel_ms = ms01;
+    ctx->stats.total_ms = ms02;
+    if (h[CNT_NOT_UNIT]) return PT_ERR_DIRECTION_NOT_UNIT;
+    return PT_OK;
+}
+
+extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum) {
+    if (!ctx || !cfg || !h_rgb_sum) return PT_ERR_BAD_ARG;
+    const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
+    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    if (rc != PT_OK) return rc;
+    rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
+    if (rc != PT_OK && rc != PT_ERR_DIRECTION_NOT_UNIT) return rc;
+    const size_t off = (size_t)cfg->idx_start * 3u, cnt = (size_t)(cfg->idx_stop - cfg->idx_start) * 3u;
+    if (cnt) HIP_TRY(ctx, hipMemcpy(h_rgb_sum + off, ctx->d_tmp + off, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    return rc;
+}
+
+extern "C" int ptgpu_render_mean_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_mean) {
+    if (!ctx || !cfg || !h_rgb_mean) return PT_ERR_BAD_ARG;
+    const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
+    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    if (rc != PT_OK) return rc;
+    rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
+    if (rc != PT_OK && rc != PT_ERR_DIRECTION_NOT_UNIT) return rc;
+    const uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    if (npix) {
+        const float k1 = 1.0f / (float)cfg->subpixels, k2 = 1.0f / (float)cfg->rays_per_subsample;
+        const uint32_t n3 = npix * 3u;
+        hipLaunchKernelGGL(pt_mean, dim3((n3 + 255u) / 256u), dim3(256), 0, nullptr, (const float *)ctx->d_tmp, cfg->idx_start, npix, k1, k2, ctx->d_tmp);
+        HIP_TRY(ctx, hipGetLastError());
+        const size_t off = (size_t)cfg->idx_start * 3u;
+        HIP_TRY(ctx, hipMemcpy(h_rgb_mean + off, ctx->d_tmp + off, (size_t)n3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return rc;
+}
+
+extern "C" int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const float *d_rgb_sum, uint8_t *d_records,
+                                    uint8_t *d_rgb8, void *stream_) {
+    if (!ctx || !cfg || !d_rgb_sum) return PT_ERR_BAD_ARG;
+    if (cfg->max_px_value != 255u) return PT_ERR_UNSUPPORTED;
+    if (cfg->idx_start > cfg->idx_stop || (uint64_t)cfg->idx_stop > (uint64_t)cfg->width * cfg->height) return PT_ERR_BAD_ARG;
+    if (cfg->subpixels == 0 || cfg->rays_per_subsample == 0) return PT_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    if (npix == 0) return PT_OK;
+    const float k1 = 1.0f / (float)cfg->subpixels, k2 = 1.0f / (float)cfg->rays_per_subsample;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + (CNT_N - 1), 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(pt_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, stream, d_rgb_sum, cfg->idx_start, npix, k1, k2,
+                       (float)cfg->max_px_value, d_records, d_rgb8, ctx->d_counters);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    return PT_OK;
+}
+
+extern "C" int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *slice, size_t slice_len, uint32_t header_size,
+                                uint32_t px_size) {
+    if (!ctx || !cfg || !slice) return PT_ERR_BAD_ARG;
+    if (cfg->max_px_value != 255u || px_size != 12u) return PT_ERR_UNSUPPORTED;
+    if (cfg->idx_start > cfg->idx_stop) return PT_ERR_BAD_ARG;
+    const uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    if ((size_t)header_size + (size_t)cfg->idx_stop * px_size > slice_len) return PT_ERR_NO_SPACE;
+    const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
+    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    if (rc != PT_OK) return rc;
+    rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
+    if (rc != PT_OK) return rc; // DirectionIsNotUnitVector aborts render() (renderers/ppm_image.zig:66 `try`)
+    if (npix == 0) return PT_OK;
+    const pt_stats keep = ctx->stats;
+    rc = ensure(ctx, (void **)&ctx->d_rec, &ctx->rec_bytes, (size_t)npix * 12u);
+    if (rc != PT_OK) return rc;
+    rc = ptgpu_resolve_device(ctx, cfg, ctx->d_tmp, ctx->d_rec, nullptr, nullptr);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpy(slice + header_size + (size_t)cfg->idx_start * px_size, ctx->d_rec, (size_t)npix * 12u, hipMemcpyDeviceToHost));
+    ctx->stats = keep;
+    return PT_OK;
+}
+
+extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n, float t_min, float t_max) {
+    if (!ctx || !in || !out) return PT_ERR_BAD_ARG;
+    if (n == 0) return PT_OK;
+    size_t in_stride = 0, out_stride = 0;
+    switch (fn) {
+    case PT_FN_CAST_RAY: in_stride = 18; out_stride = 7; break;
+    case PT_FN_SCATTER: in_stride = 27; out_stride = 4; break;
+    case PT_FN_SPHERE_HIT: in_stride = 12; out_stride = 8; break;
+    case PT_FN_SCENE_HIT: in_stride = 6; out_stride = 8; break;
+    case PT_FN_REFRACT: in_stride = 7; out_stride = 4; break;
+    case PT_FN_SCHLICK: in_stride = 2; out_stride = 1; break;
+    case PT_FN_REFLECT: in_stride = 6; out_stride = 3; break;
+    case PT_FN_LERP: in_stride = 9; out_stride = 4; break;
+    case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
+    default: return PT_ERR_UNSUPPORTED;
+    }
+    if (fn == PT_FN_SCENE_HIT && !ctx->d_geom) return PT_ERR_BAD_ARG;
+    if (fn == PT_FN_CAST_RAY && !ctx->have_camera) return PT_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_in, in_stride * n * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&d_out, out_stride * n * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(d_in); ctx->last_hip = (int)e; return PT_ERR_OOM; }
+    int rc = PT_OK;
+    e = hipMemcpy(d_in, in, in_stride * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        Cam cam = ctx->have_camera ? ctx->cam : Cam();
+        if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER)
+            hipLaunchKernelGGL(pt_debug_eval_rng, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam);
+        else
+            hipLaunchKernelGGL(pt_debug_eval, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam,
+                               (const float4 *)ctx->d_geom, (const float4 *)ctx->d_mat, (const uint32_t *)ctx->d_kind, ctx->nspheres, t_min, t_max);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, out_stride * n * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) { ctx->last_hip = (int)e; rc = PT_ERR_HIP; }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}

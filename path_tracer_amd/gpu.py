@@ -1,0 +1,112 @@
+"""GpuContext — thin Python handle on a libptgpu context (one GPU).
+
+Everything here goes through the C ABI of include/ptgpu.h; nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PT_OK, PtGpuError, check, pt_camera, pt_config, pt_stats
+
+
+class GpuContext:
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        check(self._L.ptgpu_create(int(device), C.byref(self._h)), "ptgpu_create")
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._L.ptgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads -------------------------------------------------------------------
+    def set_scene(self, spheres):
+        sp = np.ascontiguousarray(spheres, dtype=_lib.SPHERE_DTYPE)
+        check(self._L.ptgpu_set_scene(self._h, sp.ctypes.data, len(sp)), "ptgpu_set_scene")
+        self.nspheres = len(sp)
+
+    def set_camera(self, cam):
+        if not isinstance(cam, pt_camera):
+            c = pt_camera()
+            C.memmove(C.byref(c), C.byref(cam), C.sizeof(pt_camera))
+            cam = c
+        check(self._L.ptgpu_set_camera(self._h, C.byref(cam)), "ptgpu_set_camera")
+
+    @staticmethod
+    def as_config(cfg):
+        if isinstance(cfg, pt_config):
+            return cfg
+        c = pt_config()
+        assert C.sizeof(cfg) == C.sizeof(pt_config)
+        C.memmove(C.byref(c), C.byref(cfg), C.sizeof(pt_config))
+        return c
+
+    # ---- renders ---------------------------------------------------------------------
+    def render_sum(self, cfg, allow_not_unit=False):
+        """Radiance sums as an (H, W, 3) float32 array (ptgpu_render_sum_host)."""
+        cfg = self.as_config(cfg)
+        out = np.zeros((cfg.height, cfg.width, 3), dtype=np.float32)
+        rc = self._L.ptgpu_render_sum_host(self._h, C.byref(cfg), out.ctypes.data)
+        if rc != PT_OK and not (allow_not_unit and rc == _lib.PT_ERR_DIRECTION_NOT_UNIT):
+            raise PtGpuError(rc, "ptgpu_render_sum_host")
+        return out
+
+    def render_mean(self, cfg):
+        cfg = self.as_config(cfg)
+        out = np.zeros((cfg.height, cfg.width, 3), dtype=np.float32)
+        check(self._L.ptgpu_render_mean_host(self._h, C.byref(cfg), out.ctypes.data), "ptgpu_render_mean_host")
+        return out
+
+    def render_sum_device(self, cfg, d_ptr, stream=0):
+        """Radiance sums into device memory at address d_ptr (W*H*3 floats)."""
+        cfg = self.as_config(cfg)
+        check(self._L.ptgpu_render_sum_device(self._h, C.byref(cfg), C.c_void_p(int(d_ptr)), C.c_void_p(int(stream))),
+              "ptgpu_render_sum_device")
+
+    def resolve_device(self, cfg, d_sum, d_records=0, d_rgb8=0, stream=0):
+        cfg = self.as_config(cfg)
+        check(self._L.ptgpu_resolve_device(self._h, C.byref(cfg), C.c_void_p(int(d_sum)), C.c_void_p(int(d_records)),
+                                           C.c_void_p(int(d_rgb8)), C.c_void_p(int(stream))), "ptgpu_resolve_device")
+
+    def render_ppm(self, cfg, slice_, header_size, px_size):
+        """render() replacement: fills the pixel records of `slice_` (uint8 array)."""
+        cfg = self.as_config(cfg)
+        assert slice_.dtype == np.uint8 and slice_.flags["C_CONTIGUOUS"]
+        check(self._L.ptgpu_render_ppm(self._h, C.byref(cfg), slice_.ctypes.data, slice_.size, int(header_size),
+                                       int(px_size)), "ptgpu_render_ppm")
+
+    def debug_eval(self, fn, inputs, t_min=0.1, t_max=1000.0):
+        n_in, n_out = _lib.FN_STRIDES[fn]
+        a = np.ascontiguousarray(inputs)
+        assert a.dtype in (np.float32, np.uint32) and a.ndim == 2 and a.shape[1] == n_in
+        out = np.zeros((a.shape[0], n_out), dtype=np.float32)
+        check(self._L.ptgpu_debug_eval(self._h, int(fn), a.ctypes.data, out.ctypes.data, a.shape[0], float(t_min),
+                                       float(t_max)), "ptgpu_debug_eval")
+        return out
+
+    # ---- diagnostics -------------------------------------------------------------------
+    def stats(self):
+        st = pt_stats()
+        check(self._L.ptgpu_get_stats(self._h, C.byref(st)), "ptgpu_get_stats")
+        return st
+
+    def device_info(self):
+        cu, khz = C.c_int(), C.c_int()
+        arch = C.create_string_buffer(64)
+        check(self._L.ptgpu_device_info(self._h, C.byref(cu), C.byref(khz), arch, 64), "ptgpu_device_info")
+        return {"compute_units": cu.value, "clock_khz": khz.value, "arch": arch.value.decode()}
