@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-tracing hot path on MI355X.
+
+A "step" = one full render of BASELINE config 3 per GPU: scene 21 (488 spheres), 1920x1080,
+1024 paths per pixel (subpixels 4 x rays_per_subsample 256), depth 50, seed 456, with the
+scene/camera already resident in HBM and the fp32 radiance sums left in HBM.
+N > 1 GPUs: weak scaling by sample-range split — rank g traces samples [g*1024, (g+1)*1024) of a
+frame of N*1024 paths per pixel, then ONE RCCL reduce(SUM) of the fp32 sum buffers to rank 0 (inside
+the timed region).  value = paths traced by all ranks / max-over-ranks wall time.
+
+Rank 0 prints one JSON line (contract in the task statement) with `roofline` (FP32 VALU) and,
+at N = 1, `cpu_baseline` (the oracle's C restatement timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch  # imported BEFORE libptgpu: torch bundles its own HIP runtime; one runtime per process
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU = 157.3e12  # FLOP/s per MI355X: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def algorithmic_flops(paths, rays, nspheres):
+    """18 FLOP per ray-sphere test + 60 per ray + 40 per path."""
+    return rays * nspheres * 18.0 + rays * 60.0 + paths * 40.0
+
+
+def cpu_baseline(width, depth, seed):
+    """The oracle (C restatement of the reference algorithm, reference's thread split) on a bounded
+    sample of the same workload: scene 21 at the same resolution and depth, 1 path per pixel."""
+    from oracle import oracle
+    oracle.build()
+    cores = min(16, os.cpu_count() or 1)      # the GPU box's CPU share for one GPU is 16
+    threads = 2 * cores                        # main.zig:143-145: two threads per logical CPU
+    spheres, _ = oracle.setup_scene(21, seed)
+    cam = oracle.camera_preset(21)
+    img = oracle.image_new(width)
+    cfg = oracle.make_config(img, subpixels=1, rays_per_subsample=1, rebounds=depth, seed=seed)
+    t0 = time.perf_counter()
+    rc, _, st = oracle.render_sum(spheres, cam, cfg, nthreads=threads)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": st.paths / dt, "unit": "paths/s", "cores": cores, "threads": threads, "kind": "port",
+            "mrays_per_s": st.rays / dt * 1e-6, "seconds": dt,
+            "sample": "scene 21 %dx%d depth %d, 1 path/pixel (%d paths, %d rays), oracle C restatement, "
+                      "contiguous ceil(P/T) pixel chunks over T=%d pthreads" % (img.width, img.height, depth, st.paths,
+                                                                                 st.rays, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=256, help="rays_per_subsample per GPU (x4 subpixels = paths/pixel)")
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=456)
+    ap.add_argument("--chunk", type=int, default=64, help="samples per GPU work item")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from path_tracer_amd import host
+    from path_tracer_amd.distributed import gpu_render_into, render_sum_distributed
+    from path_tracer_amd.gpu import GpuContext
+
+    img = host.Image(args.width)
+    # weak scaling: N ranks trace N x (4 x spp) paths per pixel in total
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=args.spp * world, rebounds=args.depth)
+    scene = host.Scene().setupScene(args.seed, 21)
+    camera = host.Camera.preset(21, img.aspect_ratio)
+    gpu = GpuContext(local_rank)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(camera.pod)
+    render_into = gpu_render_into(gpu)
+    frame = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device="cuda")
+
+    def step():
+        render_sum_distributed(render_into, img, rt, args.seed, split="samples", chunk=args.chunk, frame=frame)
+        return gpu.stats()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, paths, rays = [], 0, 0
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st.kernel_ms)   # HIP events around the megakernel, on the stream it ran on
+        paths += st.paths
+        rays += st.rays
+    fence()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(paths), float(rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max = float(mx[0])
+    else:
+        dt_max = dt
+    all_paths, all_rays = float(tot[1]), float(tot[2])
+
+    if rank == 0:
+        nsph = len(scene.spheres)
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        flops_per_launch = algorithmic_flops(paths / args.steps, rays / args.steps, nsph)
+        achieved = flops_per_launch / (k_ms * 1e-3)
+        out = {
+            "metric": "paths/sec (scene 21, 1920x1080, 1024 spp, depth 50)",
+            "value": all_paths / dt_max,
+            "unit": "paths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: scene 21 (488 spheres, seed %d), %dx%d, %d paths/pixel per GPU "
+                                   "(subpixels 4 x %d), depth %d" % (args.seed, img.width, img.height, 4 * args.spp,
+                                                                       args.spp, args.depth),
+                       "parallelism": "sample-range split x%d + RCCL reduce(SUM) of fp32 sums" % world if world > 1 else "1 GPU",
+                       "chunk": args.chunk, "global_paths_per_pixel": 4 * args.spp * world},
+            "mrays_per_s": all_rays / dt_max * 1e-6,
+            "rays_per_path": all_rays / all_paths,
+            "roofline": {"bound": "valu", "achieved": achieved * 1e-12, "peak": PEAK_FP32_VALU * 1e-12, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU, "traffic": None,
+                         "kernel": "pt_megakernel", "kernel_ms": k_ms,
+                         "flops_per_launch": flops_per_launch,
+                         "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d); algorithmic FLOPs = "
+                                 "18/ray-sphere test + 60/ray + 40/path over the device-counted rays of rank 0's launch"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,13 @@ typedef struct pt_camera {
  * and the partial sums of a pixel are then added in chunk order.  chunk = 0 (or
  * >= the range) reproduces the reference's single sequential sum exactly.
  * mode 1 = deterministic: every random draw returns 0.5 (pixel-centre rays, zero
- * lens offset, scatter vector (0.5,0.5,0.5), dielectric xi = 0.5). */
+ * lens offset, scatter vector (0.5,0.5,0.5), dielectric xi = 0.5).
+ * Tile split (multi-GPU, large frames): with tile_pixels = T > 0 the range is cut into
+ * runs of T consecutive pixel indices starting at idx_start (which must be a multiple
+ * of T); run number t is rendered only by the owner with tile_index == t % tile_count,
+ * so that cheap (sky) and expensive rows are dealt round-robin instead of in the
+ * reference's contiguous bands (multithreading.zig:40-44).  Pixels of other owners are
+ * left untouched. */
 typedef struct pt_config {
     uint32_t width, height;                 /* Image.width/.height                  */
     uint32_t subpixels, rays_per_subsample; /* raytracer.zig:18,22                  */
@@ -95,6 +101,9 @@ typedef struct pt_config {
     uint32_t sample_start, sample_stop;
     uint32_t chunk;
     uint32_t max_px_value;                  /* Image.max_px_value (255)             */
+    uint32_t tile_pixels;                   /* tile split: pixels per tile, 0 = off */
+    uint32_t tile_count, tile_index;        /* tile t of the range belongs to owner t % tile_count */
+    uint32_t reserved;                      /* must be 0                            */
 } pt_config;
 
 /* Counters of the last render on a context. */

@@ -31,7 +31,9 @@ class Config(C.Structure):
                 ("blend_start", C.c_float * 3), ("blend_stop", C.c_float * 3),
                 ("idx_start", C.c_uint32), ("idx_stop", C.c_uint32),
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
-                ("chunk", C.c_uint32), ("max_px_value", C.c_uint32)]
+                ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
+                ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class Image(C.Structure):
@@ -182,7 +184,8 @@ def image_new(width, aspect=ASPECT_16_9, max_px_value=255):
 
 
 def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed=0, t_min=0.1, t_max=1000.0,
-                idx_start=0, idx_stop=None, sample_start=0, sample_stop=0, chunk=0):
+                idx_start=0, idx_stop=None, sample_start=0, sample_stop=0, chunk=0, tile_pixels=0, tile_count=1,
+                tile_index=0):
     """RayTracerConfig as main.zig:85-91 sets it, plus the work range."""
     cfg = Config()
     cfg.width, cfg.height = img.width, img.height
@@ -195,6 +198,7 @@ def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed
     cfg.idx_stop = img.width * img.height if idx_stop is None else idx_stop
     cfg.sample_start, cfg.sample_stop, cfg.chunk = sample_start, sample_stop, chunk
     cfg.max_px_value = img.max_px_value
+    cfg.tile_pixels, cfg.tile_count, cfg.tile_index = tile_pixels, tile_count, tile_index
     return cfg
 
 

@@ -432,6 +432,10 @@ static int render_range(const orc_sphere *sp, uint32_t n, const orc_camera *cam,
     uint64_t paths = 0;
     int rc_all = ORC_OK;
     for (uint32_t idx = i0; idx < i1; idx++) {
+        if (cfg->tile_pixels) { /* multi-GPU tile split: only this owner's runs */
+            const uint32_t t = (idx - cfg->idx_start) / cfg->tile_pixels;
+            if (t % cfg->tile_count != cfg->tile_index) continue;
+        }
         vec3 total = v3(0.0f, 0.0f, 0.0f);
         int first = 1;
         for (uint32_t c0 = s0; c0 < s1; c0 += chunk) {

@@ -54,6 +54,7 @@ typedef struct orc_config {
     uint32_t sample_start, sample_stop;
     uint32_t chunk;
     uint32_t max_px_value;
+    uint32_t tile_pixels, tile_count, tile_index, reserved; /* interleaved tile ownership (multi-GPU split) */
 } orc_config;
 
 typedef struct orc_image {

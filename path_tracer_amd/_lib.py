@@ -50,7 +50,9 @@ class pt_config(C.Structure):
                 ("blend_start", C.c_float * 3), ("blend_stop", C.c_float * 3),
                 ("idx_start", C.c_uint32), ("idx_stop", C.c_uint32),
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
-                ("chunk", C.c_uint32), ("max_px_value", C.c_uint32)]
+                ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
+                ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class pt_stats(C.Structure):
@@ -59,7 +61,7 @@ class pt_stats(C.Structure):
                 ("total_ms", C.c_double)]
 
 
-assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 88
+assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104
 
 # every symbol include/ptgpu.h declares
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",

@@ -54,7 +54,10 @@ struct KParams {
     uint32_t width, height;
     uint32_t rebounds;
     uint32_t seed_lo, seed_hi;
-    uint32_t idx_start, npix;       // pixel range [idx_start, idx_start + npix)
+    uint32_t idx_start, idx_stop;   // pixel range
+    uint32_t npix;                  // pixel slots this launch owns (all of the range, or this owner's tiles)
+    uint32_t tile_pixels, tile_count, tile_index; // interleaved tile ownership (0 = off)
+    uint32_t direct;                // 1: one chunk, sums go straight to the frame at pixel*3
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
     uint32_t nspheres;
     uint32_t total_threads;
@@ -62,10 +65,19 @@ struct KParams {
     const float4 *geom; // (cx, cy, cz, radius)
     const float4 *mat;  // (albedo r, g, b, param)
     const uint32_t *kind;
-    float *part;        // [nchunks][npix][3] partial sums
+    float *part;        // direct ? frame[W*H][3] : [nchunks][npix][3] partial sums
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
 };
+
+// Pixel index of local slot `po`: the range itself, or the owner's interleaved tiles
+// (tile t of the range belongs to owner t % tile_count; include/ptgpu.h).
+__device__ __forceinline__ uint32_t slot_to_pixel(uint32_t po, uint32_t idx_start, uint32_t tile_pixels, uint32_t tile_count,
+                                                  uint32_t tile_index) {
+    if (tile_pixels == 0u) return idx_start + po;
+    const uint32_t k = po / tile_pixels, r = po - k * tile_pixels;
+    return idx_start + (k * tile_count + tile_index) * tile_pixels + r;
+}
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -138,12 +150,13 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                     if (item < total_items) {
                         const uint32_t k = item / P.npix;
                         const uint32_t po = item - k * P.npix;
-                        pixel = P.idx_start + po;
+                        pixel = slot_to_pixel(po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
                         sample = P.s0 + k * P.chunk;
                         s_end = min(sample + P.chunk, P.s1);
-                        out_slot = item; // part[k][po]
+                        out_slot = P.direct ? pixel : item; // frame[pixel] or part[k][po]
                         accum = v3(0.f, 0.f, 0.f);
-                        has_item = true;
+                        has_item = pixel < P.idx_stop;      // the owner's last tile may be cut by the range
+                        if (!has_item) s_end = sample;
                         n_paths += s_end - sample;
                     } else {
                         alive = false;
@@ -309,12 +322,16 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
 }
 
 // Sum the chunk partials of a pixel in chunk order: total = p0; total += p1; ...
-__global__ void pt_sum_chunks(const float *part, uint32_t npix, uint32_t nchunks, uint32_t idx_start, float *rgb_sum) {
+__global__ void pt_sum_chunks(const float *part, uint32_t npix, uint32_t nchunks, uint32_t idx_start, uint32_t idx_stop,
+                              uint32_t tile_pixels, uint32_t tile_count, uint32_t tile_index, float *rgb_sum) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // over npix*3
     if (i >= npix * 3u) return;
+    const uint32_t po = i / 3u, c = i - po * 3u;
+    const uint32_t pixel = slot_to_pixel(po, idx_start, tile_pixels, tile_count, tile_index);
+    if (pixel >= idx_stop) return;
     float total = part[i];
     for (uint32_t k = 1; k < nchunks; ++k) total = total + part[(size_t)k * npix * 3u + i];
-    rgb_sum[(size_t)idx_start * 3u + i] = total;
+    rgb_sum[(size_t)pixel * 3u + c] = total;
 }
 
 // renderers/ppm_image.zig:70 — the two reciprocal multiplies
@@ -645,7 +662,10 @@ static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, u
     const uint64_t np = (uint64_t)cfg->width * cfg->height;
     if (np > 0x7fffffffull / 3) return PT_ERR_BAD_ARG;
     if (cfg->idx_start > cfg->idx_stop || cfg->idx_stop > np) return PT_ERR_BAD_ARG;
-    if (cfg->mode > 1) return PT_ERR_BAD_ARG;
+    if (cfg->mode > 1 || cfg->reserved != 0) return PT_ERR_BAD_ARG;
+    if (cfg->tile_pixels != 0 &&
+        (cfg->tile_count == 0 || cfg->tile_index >= cfg->tile_count || cfg->idx_start % cfg->tile_pixels != 0))
+        return PT_ERR_BAD_ARG;
     const uint64_t S = (uint64_t)cfg->subpixels * cfg->rays_per_subsample;
     if (S > 0xffffffffull) return PT_ERR_BAD_ARG;
     uint32_t a = cfg->sample_start, b = cfg->sample_stop;
@@ -664,7 +684,12 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     if (!d_rgb_sum) return PT_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    uint32_t npix = cfg->idx_stop - cfg->idx_start;
+    if (cfg->tile_pixels != 0) { // slots of this owner's tiles (the last one may be cut by idx_stop)
+        const uint32_t ntiles = (npix + cfg->tile_pixels - 1) / cfg->tile_pixels;
+        const uint32_t mine = (ntiles > cfg->tile_index) ? (ntiles - cfg->tile_index + cfg->tile_count - 1) / cfg->tile_count : 0;
+        npix = mine * cfg->tile_pixels;
+    }
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (npix == 0 || s1 == s0) return PT_OK;
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
@@ -675,7 +700,7 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
 
     float *part = nullptr;
     if (nchunks == 1) {
-        part = d_rgb_sum + (size_t)cfg->idx_start * 3u; // write sums in place
+        part = d_rgb_sum; // one chunk: sums go straight to the frame
     } else {
         rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, (size_t)nchunks * npix * 3u * sizeof(float));
         if (rc != PT_OK) return rc;
@@ -693,7 +718,9 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     P.width = cfg->width; P.height = cfg->height;
     P.rebounds = cfg->rebounds;
     P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
-    P.idx_start = cfg->idx_start; P.npix = npix;
+    P.idx_start = cfg->idx_start; P.idx_stop = cfg->idx_stop; P.npix = npix;
+    P.tile_pixels = cfg->tile_pixels; P.tile_count = cfg->tile_count; P.tile_index = cfg->tile_index;
+    P.direct = (nchunks == 1) ? 1u : 0u;
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
@@ -720,7 +747,8 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     if (nchunks > 1) {
         const uint32_t n3 = npix * 3u;
-        hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)part, npix, nchunks, cfg->idx_start, d_rgb_sum);
+        hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)part, npix, nchunks, cfg->idx_start, cfg->idx_stop,
+                           cfg->tile_pixels, cfg->tile_count, cfg->tile_index, d_rgb_sum);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, stream));

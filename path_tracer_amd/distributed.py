@@ -1,0 +1,76 @@
+"""Multi-GPU rendering: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Replaces the reference's only work split — contiguous pixel chunks over OS threads
+(multithreading.zig:40-44, main.zig:142-165) — with the two splits of a node of GPUs:
+
+  "samples"  every rank traces samples [g*S/G, (g+1)*S/G) of EVERY pixel into a full-frame
+             fp32 sum buffer; one reduce(SUM) to rank 0 over RCCL adds the G buffers.  For
+             high-spp frames (BASELINE config 4).  Philox streams are keyed by the global
+             sample index, so the image does not depend on G beyond fp32 add order.
+  "tiles"    the frame is cut into runs of `tile_pixels` consecutive pixels, dealt round-robin
+             to the ranks (sky rows are cheap: contiguous bands would be unbalanced); each
+             rank leaves the other ranks' pixels at 0, so the same reduce(SUM) assembles the
+             frame exactly (x + 0 = x): identical bits to a single-GPU render.  For large
+             frames / scenes (BASELINE config 5).
+
+The path has exactly one exchange step — that reduce; nothing else is communicated (the scene
+is a few KB..MB and is replicated).
+"""
+import torch
+import torch.distributed as dist
+
+from .host import make_pt_config
+
+
+def sample_range(total_samples, world, rank):
+    """[g*S/G, (g+1)*S/G) — SURVEY.md §8(e)."""
+    return (rank * total_samples) // world, ((rank + 1) * total_samples) // world
+
+
+def plan(img, rt, seed, world, rank, split="samples", chunk=0, deterministic=False, tile_pixels=256,
+         samples_per_rank=None):
+    """The pt_config rank `rank` of `world` renders.
+
+    samples_per_rank (weak scaling): each rank traces that many samples and the frame's total
+    becomes world*samples_per_rank (rt.rays_per_subsample is scaled up accordingly).
+    """
+    if split == "samples":
+        total = rt.subpixels * rt.rays_per_subsample
+        s0, s1 = sample_range(total, world, rank)
+        if s1 == s0:  # more ranks than samples: an empty range must not mean "all samples"
+            return None
+        return make_pt_config(img, rt, seed, deterministic=deterministic, sample_start=s0, sample_stop=s1, chunk=chunk)
+    if split == "tiles":
+        return make_pt_config(img, rt, seed, deterministic=deterministic, chunk=chunk, tile_pixels=tile_pixels,
+                              tile_count=world, tile_index=rank)
+    raise ValueError("split must be 'samples' or 'tiles'")
+
+
+def render_sum_distributed(render_into, img, rt, seed, split="samples", chunk=0, deterministic=False, tile_pixels=256,
+                           device="cuda", group=None, frame=None):
+    """Every rank renders its share into a zeroed full-frame buffer and the buffers are summed
+    on rank 0 (dist.reduce, RCCL for CUDA tensors).  `render_into(cfg, frame_tensor)` is the
+    single-GPU render (GpuContext.render_sum_device on frame.data_ptr()).  Returns the frame
+    tensor (complete on rank 0 only)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if frame is None:
+        frame = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device=device)
+    else:
+        frame.zero_()
+    cfg = plan(img, rt, seed, world, rank, split, chunk, deterministic, tile_pixels)
+    if cfg is not None:
+        render_into(cfg, frame)
+    if world > 1:
+        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return frame
+
+
+def gpu_render_into(gpu):
+    """render_into for a GpuContext: enqueue on torch's current stream, device memory only."""
+
+    def fn(cfg, frame):
+        assert frame.is_cuda and frame.dtype == torch.float32 and frame.is_contiguous()
+        gpu.render_sum_device(cfg, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+    return fn

@@ -1,0 +1,37 @@
+"""Quick single-GPU throughput probe (development tool, not the benchmark)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # before libptgpu: one HIP runtime per process (torch bundles its own)
+torch.cuda.init()
+import numpy as np
+from oracle import oracle as o
+from path_tracer_amd.gpu import GpuContext
+
+def main():
+    width = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
+    spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16      # rays_per_subsample (x4 subpixels)
+    depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    scene = int(sys.argv[5]) if len(sys.argv) > 5 else 21
+    if scene > 100:
+        sp = o.scene_synthetic(scene, 1); cam = o.camera_preset(21)
+    else:
+        sp, _ = o.setup_scene(scene, 456); cam = o.camera_preset(scene)
+    img = o.image_new(width)
+    cfg = o.make_config(img, subpixels=4, rays_per_subsample=spp, rebounds=depth, seed=456, chunk=chunk)
+    g = GpuContext(0)
+    info = g.device_info()
+    g.set_scene(sp); g.set_camera(cam)
+    buf = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device="cuda")
+    for it in range(3):
+        t = time.time(); g.render_sum_device(cfg, buf.data_ptr()); dt = time.time() - t
+        st = g.stats()
+        tests = st.rays * len(sp)
+        flops = tests * 18 + st.rays * 60 + st.paths * 40
+        print("iter %d: wall %.3fs kernel %.1f ms paths %.3e rays %.3e (%.2f rays/path) cands/ray %.2f | %.3e paths/s %.1f Mrays/s %.2f Gtests/s %.1f TFLOP/s (%.1f%% of 157.3)" % (
+            it, dt, st.kernel_ms, st.paths, st.rays, st.rays / st.paths, st.candidates / st.rays,
+            st.paths / (st.kernel_ms * 1e-3), st.rays / (st.kernel_ms * 1e-3) * 1e-6, tests / (st.kernel_ms * 1e-3) * 1e-9,
+            flops / (st.kernel_ms * 1e-3) * 1e-12, flops / (st.kernel_ms * 1e-3) / 157.3e12 * 100), flush=True)
+    print(info)
+
+main()
