@@ -113,6 +113,8 @@ typedef struct pt_stats {
     uint64_t sphere_tests; /* rays * n_spheres (what the reference's scan performs)  */
     uint64_t candidates;   /* exact Sphere.is_hit evaluations after the LDS filter   */
     uint64_t not_unit;     /* lerp() directions failing illumination.zig:29          */
+    uint64_t wave_steps;   /* ray steps executed by waves (rays / (64*wave_steps) = lane utilisation) */
+    uint64_t flush_iters;  /* wave iterations of the exact-test loop                 */
     double kernel_ms;      /* HIP-event time of the path-tracing kernel              */
     double total_ms;       /* kernel + resolve (+ copies for host-pointer variants)  */
 } pt_stats;

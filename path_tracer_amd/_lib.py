@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptgpu.so")
+LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "libptgpu.so")  # PTGPU_LIB: diagnostic builds (tools/)
 
 PT_OK = 0
 PT_ERR_BAD_ARG = -1
@@ -57,7 +57,8 @@ class pt_config(C.Structure):
 
 class pt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("kernel_ms", C.c_double),
+                ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
+                ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double)]
 
 

@@ -9,10 +9,11 @@
 //     ballot/popcount) — replaces the thread split of multithreading.zig;
 //   * Scene.is_hit (scene.zig:96-110) = a linear scan over a filter table
 //     (cx,cy,cz,threshold) staged into LDS in tiles: 7 FMAs + 1 compare per sphere
-//     decide conservatively whether the reference's discriminant can be >= 0; the
-//     few survivors are queued per lane (LDS) and evaluated afterwards with the
-//     reference's exact arithmetic (sphere.zig:63-103), in list order, so the
-//     closest hit is the reference's bit for bit;
+//     decide conservatively whether the reference's discriminant can be >= 0 and one
+//     v_addc shifts the verdict into a per-lane bit word (no branch in the scan); the
+//     few survivors are evaluated afterwards with the reference's exact arithmetic
+//     (sphere.zig:63-103), in sphere order, so the closest hit is the reference's bit
+//     for bit;
 //   * radiance (illumination.zig:76-90) = iterative bounce loop; the hit sphere of
 //     every bounce is pushed on a per-lane stack in HBM and the attenuations are
 //     multiplied innermost-first when the path ends, as the recursion does.
@@ -40,12 +41,12 @@ using namespace ptdev;
 namespace {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
-constexpr int kTile = 1024;          // spheres per LDS tile (16 KiB of float4)
+constexpr int kTile = 512;           // spheres per tile: 16 candidate-mask words per lane (and 8 KiB of float4 when LDS-fed)
+constexpr int kMaskWords = kTile / 32;
 constexpr int kSub = 4;              // spheres per software-pipeline stage (one s_load_dwordx16)
-constexpr int kCandCap = 32;         // candidate slots per lane (u16 tile-relative ids, slot-major in LDS)
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_N = 8 };
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 16 };
 
 struct KParams {
     Cam cam;
@@ -85,31 +86,38 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// Diagnostic build only (-DPT_PHASE_TIMING, tools/build_prof.sh): per-wave s_memtime stamps
+// around the phases, summed into counters[8..15]; the shipped library has no stamps.
+#ifdef PT_PHASE_TIMING
+#define PT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PT_ACC(idx, a, b) t_phase[idx] += (b) - (a)
+#else
+#define PT_STAMP(var)
+#define PT_ACC(idx, a, b)
+#endif
+
 // ---------------------------------------------------------------------------
 // the megakernel
 // ---------------------------------------------------------------------------
-// FEED selects how the wave-uniform filter records reach the VALU:
-//   FEED_SGPR      scalar loads (s_load_dwordx16 = 4 records) through the scalar cache
-//                  into SGPRs, used directly as VALU operands: no VGPRs, no LDS reads;
-//   FEED_LDS       the whole table staged once into an LDS tile, broadcast ds_read_b128;
-//   FEED_LDS_TILES tables larger than one tile: tiles restaged per ray step (block-wide).
-enum { FEED_SGPR = 0, FEED_LDS = 1, FEED_LDS_TILES = 2 };
-
-typedef __attribute__((address_space(4))) const float4 cfloat4; // constant address space: scalar loads
-
-template <bool DET, int FEED>
+// MULTI_TILE: the filter table is larger than one LDS tile and is restaged tile by tile in
+// every ray step (block-wide barriers); otherwise it is staged once per workgroup.
+//
+// The wave-uniform filter records are read from LDS with broadcast ds_read_b128.  Feeding them
+// through the scalar cache instead (s_load_dwordx16 into SGPR operands: no VGPRs, no LDS reads)
+// was measured 15 % slower on MI355X — 16 B per wave per test saturates the scalar cache, which
+// several CUs share, long before LDS.
+template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
-    constexpr bool MULTI_TILE = (FEED == FEED_LDS_TILES);
-    constexpr uint32_t TILE = (FEED == FEED_SGPR) ? 32768u : (uint32_t)kTile; // u16 tile-relative ids
-    __shared__ float4 s_filt[(FEED == FEED_SGPR) ? 1 : kTile];
-    __shared__ uint16_t s_cand[kCandCap * kBlock];
+    constexpr uint32_t TILE = (uint32_t)kTile; // spheres per LDS staging tile = per candidate-mask tile
+    __shared__ float4 s_filt[kTile];
+    __shared__ uint32_t s_mask[kMaskWords * kBlock]; // candidate bit words, word-major (conflict-free)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * kBlock + tid;
 
     const uint32_t n_pad = (P.nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
-    if (FEED == FEED_LDS) {
+    if (!MULTI_TILE) {
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
         __syncthreads();
     }
@@ -125,10 +133,16 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
     unsigned long long n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0;
+    uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
+#ifdef PT_PHASE_TIMING
+    unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t total_items = P.npix * P.nchunks;
 
     for (;;) {
         // ---- phase A: refill lanes whose path has ended -------------------------
+        PT_STAMP(tA0);
         if (alive && need_path && sample == s_end) {
             if (has_item) {
                 float *dst = P.part + 3ull * out_slot;
@@ -183,6 +197,8 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
         }
 
         // ---- phase B: Scene.is_hit (scene.zig:96-110) ---------------------------
+        PT_STAMP(tB0);
+        PT_ACC(0, tA0, tB0);
         // conservative filter over the LDS tile(s), exact test on the survivors
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
@@ -196,48 +212,28 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
             const float wy = 2.0f * fmaf(-od, hy, o.y);
             const float wz = 2.0f * fmaf(-od, hz, o.z);
             const float E = fmaf(od, od, (kKeps - 1.0f) * oo);
-            uint32_t cnt = 0;
+            // One bit per tested sphere, 32 tests per word: after the compare, VCC is shifted
+            // into the lane's word with a single v_addc (m = m + m + vcc) — no branch, no
+            // scalar work per test.  A word's first test ends up in its highest used bit.
+            uint32_t m = 0;    // word under construction
+            uint32_t S = 0;    // one bit per stored word of this tile: "word is non-zero"
 
-            auto flush = [&](uint32_t tile_base) {
-                // exact Sphere.is_hit on this lane's queued candidates, in list order
-                n_cands += cnt;
-                for (uint32_t i = 0; __ballot(i < cnt) != 0ull; ++i) {
-                    if (i < cnt) {
-                        const uint32_t j = tile_base + s_cand[i * kBlock + tid];
-                        const float4 g = P.geom[j];
-                        float t;
-                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
-                            if (t < closest) { closest = t; hit = (int)j; }
-                        }
-                    }
-                }
-                cnt = 0;
-            };
-
-            const cfloat4 *filt_c = (const cfloat4 *)(P.filt);
             for (uint32_t tile = 0; tile < n_pad; tile += TILE) {
-                const uint32_t tn = min(TILE, n_pad - tile);
+                const uint32_t tn = min(TILE, n_pad - tile);      // multiple of 2*kSub
+                const uint32_t nw = (tn + 31u) >> 5;              // words of this tile
+                const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
                 if (MULTI_TILE) {
                     __syncthreads();
                     for (uint32_t i = tid; i < tn; i += kBlock) s_filt[i] = P.filt[tile + i];
                     __syncthreads();
                 }
-                // Software-pipelined scan: the filter records of the next kSub spheres
-                // are fetched while the current kSub are tested; two register sets,
-                // ping-pong, no copies.
+                // Software-pipelined scan: the filter records of the next kSub spheres are
+                // fetched while the current kSub are tested; two register sets, ping-pong.
                 auto load = [&](float4 (&f)[kSub], uint32_t j0) {
 #pragma unroll
-                    for (int k = 0; k < kSub; ++k) {
-                        if (FEED == FEED_SGPR) {
-                            const cfloat4 *src = filt_c + (tile + j0 + k);
-                            f[k].x = src->x; f[k].y = src->y; f[k].z = src->z; f[k].w = src->w;
-                        } else {
-                            f[k] = s_filt[j0 + k];
-                        }
-                    }
+                    for (int k = 0; k < kSub; ++k) f[k] = s_filt[j0 + k];
                 };
-                auto test = [&](const float4 (&f)[kSub], uint32_t j0) {
-                    if (__ballot(cnt > (uint32_t)(kCandCap - kSub)) != 0ull) flush(tile);
+                auto test = [&](const float4 (&f)[kSub]) {
 #pragma unroll
                     for (int k = 0; k < kSub; ++k) {
                         float q = f[k].x * hx;
@@ -247,24 +243,64 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                         s = fmaf(f[k].y, wy, s);
                         s = fmaf(f[k].z, wz, s);
                         const float F = fmaf(q, q, s);
-                        if (F >= f[k].w) {
-                            s_cand[cnt * kBlock + tid] = (uint16_t)(j0 + k);
-                            cnt++;
-                        }
+                        // candidate iff F >= T
+                        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f[k].w), "v"(F) : "vcc");
                     }
+                };
+                auto store_word = [&](uint32_t w, uint32_t tests_in_word) {
+                    const uint32_t mv = (tests_in_word >= 32u) ? m : (m & ((1u << tests_in_word) - 1u));
+                    s_mask[w * kBlock + tid] = mv;
+                    S = S + S + (mv != 0u ? 1u : 0u);
                 };
                 float4 fa[kSub], fb[kSub];
                 load(fa, 0);
-                for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) { // n_pad is a multiple of 2*kSub
+                for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) {
                     load(fb, j0 + kSub);
-                    test(fa, j0);
+                    test(fa);
                     if (j0 + 2 * kSub < tn) load(fa, j0 + 2 * kSub);
-                    test(fb, j0 + kSub);
+                    test(fb);
+                    const uint32_t done = j0 + 2 * kSub;           // tests of this tile so far
+                    if ((done & 31u) == 0u) store_word((done >> 5) - 1u, 32u);
+                    else if (done == tn) store_word(nw - 1u, g_last);
                 }
-                flush(tile); // ids are tile-relative: drain before moving on
+                // ---- exact Sphere.is_hit (sphere.zig:63-103) on the survivors, ascending sphere
+                // index, strict '<' (scene.zig:102): each lane walks its own words/bits; the
+                // wave iterates max-over-lanes(candidates) times.
+                PT_STAMP(tF0);
+                {
+                    uint32_t mw = 0, wcur = 0, gcur = 32;
+                    for (;;) {
+                        if (mw == 0u && S != 0u) {
+                            const uint32_t b = 31u - (uint32_t)__clz((int)S);
+                            S &= ~(1u << b);
+                            wcur = nw - 1u - b;
+                            gcur = (wcur == nw - 1u) ? g_last : 32u;
+                            mw = s_mask[wcur * kBlock + tid];
+                        }
+                        const bool has = mw != 0u;
+                        if (__ballot(has) == 0ull) break;
+                        n_flush_iters++;
+                        if (has) {
+                            const uint32_t b = 31u - (uint32_t)__clz((int)mw);
+                            mw &= ~(1u << b);
+                            const uint32_t j = tile + (wcur << 5) + (gcur - 1u - b);
+                            const float4 g = P.geom[j];
+                            n_cands++;
+                            float t;
+                            if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
+                                if (t < closest) { closest = t; hit = (int)j; }
+                            }
+                        }
+                    }
+                }
+                PT_STAMP(tF1);
+                PT_ACC(2, tF0, tF1);
             }
         }
         if (alive) n_rays++;
+        n_wave_steps++;
+        PT_STAMP(tC0);
+        PT_ACC(1, tB0, tC0);
 
         // ---- phase C: radiance step (illumination.zig:76-90) ---------------------
         if (alive) {
@@ -306,8 +342,16 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                 need_path = true;
             }
         }
+        PT_STAMP(tC1);
+        PT_ACC(3, tC0, tC1);
     }
 
+#ifdef PT_PHASE_TIMING
+    if (lane == 0) {
+        t_phase[4] = __builtin_amdgcn_s_memtime() - t_begin;
+        for (int i = 0; i < 5; ++i) atomicAdd(&P.counters[8 + i], t_phase[i]);
+    }
+#endif
     // ---- statistics ---------------------------------------------------------------
     n_rays = wave_sum_u64(n_rays);
     n_cands = wave_sum_u64(n_cands);
@@ -318,6 +362,8 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
         atomicAdd(&P.counters[CNT_CANDS], n_cands);
         atomicAdd(&P.counters[CNT_PATHS], n_paths);
         if (n_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], n_not_unit);
+        atomicAdd(&P.counters[CNT_WAVE_STEPS], (unsigned long long)n_wave_steps);
+        atomicAdd(&P.counters[CNT_FLUSH_ITERS], (unsigned long long)n_flush_iters);
     }
 }
 
@@ -491,7 +537,6 @@ struct ptgpu_ctx {
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     int blocks_per_cu = 4;
-    int feed = 0; // FEED_SGPR; PTGPU_FEED=lds selects the LDS-tile variant (A/B measurement)
     pt_stats stats;
 };
 
@@ -553,8 +598,6 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     if (e != hipSuccess) { delete ctx; return PT_ERR_HIP; }
     const char *bpc = getenv("PTGPU_BLOCKS_PER_CU");
     if (bpc && atoi(bpc) > 0 && atoi(bpc) <= 8) ctx->blocks_per_cu = atoi(bpc);
-    const char *feed = getenv("PTGPU_FEED");
-    if (feed && strcmp(feed, "lds") == 0) ctx->feed = 1;
     *out = ctx;
     return PT_OK;
 }
@@ -729,20 +772,15 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    int feed = ctx->feed;
-    if (feed != FEED_SGPR) feed = (ctx->n_pad > (uint32_t)kTile) ? FEED_LDS_TILES : FEED_LDS;
+    const bool multi = ctx->n_pad > (uint32_t)kTile;
     const bool det = cfg->mode == 1;
-#define PT_LAUNCH(D, F) hipLaunchKernelGGL((pt_megakernel<D, F>), dim3(grid), dim3(kBlock), 0, stream, P)
     if (det) {
-        if (feed == FEED_SGPR) PT_LAUNCH(true, FEED_SGPR);
-        else if (feed == FEED_LDS) PT_LAUNCH(true, FEED_LDS);
-        else PT_LAUNCH(true, FEED_LDS_TILES);
+        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, P);
     } else {
-        if (feed == FEED_SGPR) PT_LAUNCH(false, FEED_SGPR);
-        else if (feed == FEED_LDS) PT_LAUNCH(false, FEED_LDS);
-        else PT_LAUNCH(false, FEED_LDS_TILES);
+        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, P);
     }
-#undef PT_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
     if (nchunks > 1) {
@@ -763,6 +801,15 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     ctx->stats.sphere_tests = h[CNT_RAYS] * ctx->nspheres;
     ctx->stats.candidates = h[CNT_CANDS];
     ctx->stats.not_unit = h[CNT_NOT_UNIT];
+#ifdef PT_PHASE_TIMING
+    {
+        const double tot = (double)h[12];
+        fprintf(stderr, "[phase timing] share of wave cycles: refill %.3f  scan %.3f  (of which flush %.3f)  shade %.3f\n",
+                h[8] / tot, h[9] / tot, h[10] / tot, h[11] / tot);
+    }
+#endif
+    ctx->stats.wave_steps = h[CNT_WAVE_STEPS];
+    ctx->stats.flush_iters = h[CNT_FLUSH_ITERS];
     ctx->stats.kernel_ms = ms01;
     ctx->stats.total_ms = ms02;
     if (h[CNT_NOT_UNIT]) return PT_ERR_DIRECTION_NOT_UNIT;

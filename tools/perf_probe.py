@@ -28,6 +28,7 @@ def main():
         st = g.stats()
         tests = st.rays * len(sp)
         flops = tests * 18 + st.rays * 60 + st.paths * 40
+        print("   lane util %.3f  flush iters/step %.2f" % (st.rays / (64.0 * max(st.wave_steps, 1)), st.flush_iters / max(st.wave_steps, 1)))
         print("iter %d: wall %.3fs kernel %.1f ms paths %.3e rays %.3e (%.2f rays/path) cands/ray %.2f | %.3e paths/s %.1f Mrays/s %.2f Gtests/s %.1f TFLOP/s (%.1f%% of 157.3)" % (
             it, dt, st.kernel_ms, st.paths, st.rays, st.rays / st.paths, st.candidates / st.rays,
             st.paths / (st.kernel_ms * 1e-3), st.rays / (st.kernel_ms * 1e-3) * 1e-6, tests / (st.kernel_ms * 1e-3) * 1e-9,
