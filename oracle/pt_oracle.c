@@ -145,6 +145,13 @@ static float rng_float(rng_t *r) {
     }
     }
 }
+/* Philox path streams only: k consecutive draws never straddle a block — if the current
+ * block has fewer than k words left, skip them.  Applied to the (u,v) jitter pair, each disk
+ * try (k = 2) and each unit-sphere try (k = 3), so that a try costs the GPU one Philox call at
+ * one program point.  Other generators (Zig emulation, constant, array) are plain sequences. */
+static void rng_reserve(rng_t *r, uint32_t k) {
+    if (r->kind == RNG_PHILOX && (r->n & 3u) + k > 4u) r->n = (r->n + 3u) & ~3u;
+}
 static void rng_philox_path(rng_t *r, uint64_t seed, uint32_t pixel, uint32_t sample) {
     memset(r, 0, sizeof *r);
     r->kind = RNG_PHILOX;
@@ -210,6 +217,7 @@ static int scene_is_hit(const orc_sphere *sp, uint32_t n, ray_t ray, float t_min
 static vec3 random_vector_in_unit_sphere(rng_t *r) {
     vec3 p = v3(0, 0, 0);
     for (int tries = 0; tries < ORC_MAX_TRIES; tries++) {
+        rng_reserve(r, 3);
         const float x = rng_float(r), y = rng_float(r), z = rng_float(r);
         p = v3(x, y, z);
         if (vlen2(p) < 1.0f) return p;
@@ -220,6 +228,7 @@ static vec3 random_vector_in_unit_sphere(rng_t *r) {
 static vec3 random_vector_in_unit_disk(rng_t *r) {
     vec3 p = v3(0, 0, 0);
     for (int tries = 0; tries < ORC_MAX_TRIES; tries++) {
+        rng_reserve(r, 2);
         const float x = 2.0f * rng_float(r) - 1.0f;
         const float y = 2.0f * rng_float(r) - 1.0f;
         p = v3(x, y, 0.0f);
@@ -403,6 +412,7 @@ static int trace_sample(trace_ctx *tc, const orc_camera *cam, const orc_config *
                         rng_t *r_cam, rng_t *r_mat, int iterative, vec3 *out) {
     const uint32_t i_col = idx % cfg->width;
     const uint32_t i_row = idx / cfg->width;
+    rng_reserve(r_cam, 2);
     const float u = ((float)i_col + rng_float(r_cam)) / (float)cfg->width;
     const float v = ((float)(cfg->height - i_row + 1) + rng_float(r_cam)) / (float)cfg->height; /* sic: +1 */
     const ray_t ray = cast_ray(cam, u, v, r_cam);

@@ -33,7 +33,9 @@ __device__ __forceinline__ V3 vunit(V3 a) {
 
 // ---- random draws -----------------------------------------------------------------
 // Philox4x32-10 path stream: key = (seed lo, seed hi); counter = (pixel, sample,
-// block, 0); draw n of a path is word n&3 of block n>>2.  Replaces
+// block, 0); draw n of a path is word n&3 of block n>>2; the (u,v) jitter pair, each disk
+// try (2 draws) and each unit-sphere try (3 draws) skip to the next block when the current
+// one cannot hold them.  Replaces
 // std.rand.DefaultPrng (main.zig:100, renderers/ppm_image.zig:110, material.zig:15).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
@@ -65,15 +67,42 @@ struct PhiloxRng { // stochastic mode
         n++;
         return u32_to_float(w);
     }
+    // Two / three draws that never straddle a Philox block: if fewer words than needed
+    // are left in the current block, the rest of the block is skipped ("reserve").  A
+    // rejection-loop try therefore runs Philox at most once, and at ONE program point for
+    // all lanes of a wave, instead of possibly at each of its draws.
+    __device__ __forceinline__ void next2(float &x, float &y) {
+        uint32_t k = n & 3u;
+        if (k == 3u) { n += 1u; k = 0u; }
+        if (k == 0u) philox4x32_10(pixel, sample, n >> 2, 0u, k0, k1, b0, b1, b2, b3);
+        const uint32_t w0 = (k == 0u) ? b0 : (k == 1u) ? b1 : b2;
+        const uint32_t w1 = (k == 0u) ? b1 : (k == 1u) ? b2 : b3;
+        n += 2u;
+        x = u32_to_float(w0); y = u32_to_float(w1);
+    }
+    __device__ __forceinline__ void next3(float &x, float &y, float &z) {
+        uint32_t k = n & 3u;
+        if (k > 1u) { n = (n + 3u) & ~3u; k = 0u; }
+        if (k == 0u) philox4x32_10(pixel, sample, n >> 2, 0u, k0, k1, b0, b1, b2, b3);
+        const uint32_t w0 = (k == 0u) ? b0 : b1;
+        const uint32_t w1 = (k == 0u) ? b1 : b2;
+        const uint32_t w2 = (k == 0u) ? b2 : b3;
+        n += 3u;
+        x = u32_to_float(w0); y = u32_to_float(w1); z = u32_to_float(w2);
+    }
 };
 struct ConstRng { // deterministic mode: every draw is 0.5
     __device__ __forceinline__ void init(uint32_t, uint32_t) {}
     __device__ __forceinline__ void start_path(uint32_t, uint32_t) {}
     __device__ __forceinline__ float next() { return 0.5f; }
+    __device__ __forceinline__ void next2(float &x, float &y) { x = y = 0.5f; }
+    __device__ __forceinline__ void next3(float &x, float &y, float &z) { x = y = z = 0.5f; }
 };
 struct ArrayRng { // per-function parity vectors: draws supplied by the caller
     const float *xi; uint32_t n, cap;
     __device__ __forceinline__ float next() { const float v = (n < cap) ? xi[n] : 0.5f; n++; return v; }
+    __device__ __forceinline__ void next2(float &x, float &y) { x = next(); y = next(); }
+    __device__ __forceinline__ void next3(float &x, float &y, float &z) { x = next(); y = next(); z = next(); }
 };
 
 // The reference's rejection loops are unbounded; both the oracle and this code stop
@@ -85,9 +114,8 @@ template <class R>
 __device__ __forceinline__ V3 random_vector_in_unit_sphere(R &r) {
     V3 p = v3(0.f, 0.f, 0.f);
     for (int tries = 0; tries < PT_MAX_TRIES; ++tries) {
-        const float x = r.next();
-        const float y = r.next();
-        const float z = r.next();
+        float x, y, z;
+        r.next3(x, y, z);
         p = v3(x, y, z);
         if (vlen2(p) < 1.0f) break;
     }
@@ -98,8 +126,10 @@ template <class R>
 __device__ __forceinline__ V3 random_vector_in_unit_disk(R &r) {
     V3 p = v3(0.f, 0.f, 0.f);
     for (int tries = 0; tries < PT_MAX_TRIES; ++tries) {
-        const float x = 2.0f * r.next() - 1.0f;
-        const float y = 2.0f * r.next() - 1.0f;
+        float xi0, xi1;
+        r.next2(xi0, xi1);
+        const float x = 2.0f * xi0 - 1.0f;
+        const float y = 2.0f * xi1 - 1.0f;
         p = v3(x, y, 0.0f);
         if (vlen2(p) < 1.0f) break;
     }

@@ -189,8 +189,10 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
             rng.start_path(pixel, sample);
             const uint32_t i_col = pixel % P.width;
             const uint32_t i_row = pixel / P.width;
-            const float u = ((float)i_col + rng.next()) / (float)P.width;
-            const float v = ((float)(P.height - i_row + 1u) + rng.next()) / (float)P.height;
+            float xi_u, xi_v;
+            rng.next2(xi_u, xi_v);
+            const float u = ((float)i_col + xi_u) / (float)P.width;
+            const float v = ((float)(P.height - i_row + 1u) + xi_v) / (float)P.height;
             cast_ray(P.cam, u, v, rng, o, d);
             bounce = 0;
             need_path = false;
