@@ -823,15 +823,19 @@ extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float
     const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
     int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
     if (rc != PT_OK) return rc;
+    if (cfg->idx_start > cfg->idx_stop || (uint64_t)cfg->idx_stop > (uint64_t)cfg->width * cfg->height) return PT_ERR_BAD_ARG;
+    const size_t off = (size_t)cfg->idx_start * 3u, cnt = (size_t)(cfg->idx_stop - cfg->idx_start) * 3u;
+    // tile split: other owners' pixels inside the range must come back untouched
+    if (cfg->tile_pixels != 0 && cnt) HIP_TRY(ctx, hipMemcpy(ctx->d_tmp + off, h_rgb_sum + off, cnt * sizeof(float), hipMemcpyHostToDevice));
     rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
     if (rc != PT_OK && rc != PT_ERR_DIRECTION_NOT_UNIT) return rc;
-    const size_t off = (size_t)cfg->idx_start * 3u, cnt = (size_t)(cfg->idx_stop - cfg->idx_start) * 3u;
     if (cnt) HIP_TRY(ctx, hipMemcpy(h_rgb_sum + off, ctx->d_tmp + off, cnt * sizeof(float), hipMemcpyDeviceToHost));
     return rc;
 }
 
 extern "C" int ptgpu_render_mean_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_mean) {
     if (!ctx || !cfg || !h_rgb_mean) return PT_ERR_BAD_ARG;
+    if (cfg->tile_pixels != 0) return PT_ERR_UNSUPPORTED; // resolve whole ranges only: combine the owners' sums first
     const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
     int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
     if (rc != PT_OK) return rc;
@@ -871,7 +875,7 @@ extern "C" int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const 
 extern "C" int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *slice, size_t slice_len, uint32_t header_size,
                                 uint32_t px_size) {
     if (!ctx || !cfg || !slice) return PT_ERR_BAD_ARG;
-    if (cfg->max_px_value != 255u || px_size != 12u) return PT_ERR_UNSUPPORTED;
+    if (cfg->max_px_value != 255u || px_size != 12u || cfg->tile_pixels != 0) return PT_ERR_UNSUPPORTED;
     if (cfg->idx_start > cfg->idx_stop) return PT_ERR_BAD_ARG;
     const uint32_t npix = cfg->idx_stop - cfg->idx_start;
     if ((size_t)header_size + (size_t)cfg->idx_stop * px_size > slice_len) return PT_ERR_NO_SPACE;
