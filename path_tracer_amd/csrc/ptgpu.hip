@@ -109,8 +109,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     constexpr uint32_t TILE = (uint32_t)kTile; // spheres per LDS staging tile = per candidate-mask tile
-    __shared__ float4 s_filt[kTile];
+    __shared__ float4 s_filt[kTile];                 // (cx, cy, cz, T) filter records of the current tile
     __shared__ uint32_t s_mask[kMaskWords * kBlock]; // candidate bit words, word-major (conflict-free)
+    // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
+    // latency in the exact pass / shading); larger scenes read them from HBM/L2
+    __shared__ float s_radius[MULTI_TILE ? 1 : kTile];
+    __shared__ float4 s_mat[MULTI_TILE ? 1 : kTile];   // (albedo r, g, b, param); kind in s_kind
+    __shared__ uint8_t s_kind[MULTI_TILE ? 4 : kTile];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -119,8 +124,21 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     const uint32_t n_pad = (P.nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
     if (!MULTI_TILE) {
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
+        for (uint32_t i = tid; i < P.nspheres; i += kBlock) {
+            s_radius[i] = P.geom[i].w;
+            s_mat[i] = P.mat[i];
+            s_kind[i] = (uint8_t)P.kind[i];
+        }
         __syncthreads();
     }
+    // exact sphere / material lookups (LDS for single-tile scenes)
+    auto geom_of = [&](uint32_t j) -> float4 {
+        if (MULTI_TILE) return P.geom[j];
+        const float4 f = s_filt[j];
+        return make_float4(f.x, f.y, f.z, s_radius[j]);
+    };
+    auto mat_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.mat[j] : s_mat[j]; };
+    auto kind_of = [&](uint32_t j) -> uint32_t { return MULTI_TILE ? P.kind[j] : (uint32_t)s_kind[j]; };
 
     // per-lane path state
     bool alive = true;      // lane still has (or can get) work
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                             const uint32_t b = 31u - (uint32_t)__clz((int)mw);
                             mw &= ~(1u << b);
                             const uint32_t j = tile + (wcur << 5) + (gcur - 1u - b);
-                            const float4 g = P.geom[j];
+                            const float4 g = geom_of(j);
                             n_cands++;
                             float t;
                             if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
@@ -313,9 +331,9 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                 if (bounce == P.rebounds) {
                     done = true; // illumination.zig:80-81: black
                 } else {
-                    const float4 g = P.geom[hit];
-                    const float4 m = P.mat[hit];
-                    const uint32_t kind = P.kind[hit];
+                    const float4 g = geom_of((uint32_t)hit);
+                    const float4 m = mat_of((uint32_t)hit);
+                    const uint32_t kind = kind_of((uint32_t)hit);
                     V3 p, n;
                     sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, n);
                     const V3 nd = scatter(kind, m.w, d, p, n, rng);
@@ -328,8 +346,8 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                 // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
                 for (uint32_t b = bounce; b > 0; --b) {
                     const uint32_t id = P.stack[(size_t)(b - 1) * P.total_threads + gtid];
-                    if (P.kind[id] != 2u) {
-                        const float4 m = P.mat[id];
+                    if (kind_of(id) != 2u) {
+                        const float4 m = mat_of(id);
                         color = vemul(color, v3(m.x, m.y, m.z));
                     } else {
                         color = vemul(color, v3(1.0f, 1.0f, 1.0f)); // material.zig:135
