@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
 #ifdef PT_PHASE_TIMING
     unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
     const uint32_t total_items = P.npix * P.nchunks;
 
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
 #ifdef PT_PHASE_TIMING
     if (lane == 0) {
         t_phase[4] = __builtin_amdgcn_s_memtime() - t_begin;
+        atomicAdd(&P.counters[13], __builtin_amdgcn_s_memrealtime() - r_begin);
         for (int i = 0; i < 5; ++i) atomicAdd(&P.counters[8 + i], t_phase[i]);
     }
 #endif
@@ -824,6 +826,7 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
 #ifdef PT_PHASE_TIMING
     {
         const double tot = (double)h[12];
+        fprintf(stderr, "[phase timing] shader clock %.0f MHz (s_memtime / s_memrealtime)\n", tot / (double)h[13] * 100.0);
         fprintf(stderr, "[phase timing] share of wave cycles: refill %.3f  scan %.3f  (of which flush %.3f)  shade %.3f\n",
                 h[8] / tot, h[9] / tot, h[10] / tot, h[11] / tot);
     }

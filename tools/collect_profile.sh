@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): collects the rocprofv3 evidence kept under profiles/.
+#   1. kernel-trace stats of the default bench.py run
+#   2. SQ counter passes (separate runs, no tracing) on a shorter bench run
+# usage: tools/collect_profile.sh <round-tag>
+set -u
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/profile_$tag
+mkdir -p $out
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.err || exit 1
+pass() { # name, counters...
+  local name=$1; shift
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o p -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --spp 64 > $out/$name.json 2> $out/$name.err || exit 1
+}
+pass pmc_valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY
+pass pmc_lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM
+pass pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
+ls -R $out | head -40

@@ -1,0 +1,41 @@
+"""Condenses gpurun_out/profile_<tag>/ (tools/collect_profile.sh) into profiles/<tag>_*.{csv,md}."""
+import csv, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = "gpurun_out/profile_%s" % tag
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), "profiles/%s_bench_kernel_stats.csv" % tag)
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), "profiles/%s_bench_under_rocprof.json" % tag)
+vals = {}
+for name in ("pmc_valu", "pmc_lds", "pmc_grbm"):
+    with open(os.path.join(src, name, "p_counter_collection.csv")) as f:
+        for row in csv.DictReader(f):
+            if "megakernel" not in row["Kernel_Name"]:
+                continue
+            vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    bench = json.load(open(os.path.join(src, name + ".json")))
+kms = bench["roofline"]["kernel_ms"]
+lines = ["# %s — SQ counters of pt_megakernel (one launch: 1080p, 256 paths/pixel, depth 50)" % tag, "",
+         "Collected by tools/collect_profile.sh in separate --pmc passes (no tracing).", "", "| counter | value |", "|---|---|"]
+for k in sorted(vals):
+    lines.append("| %s | %.6g |" % (k, vals[k]))
+wc = vals["SQ_WAVE_CYCLES"]
+waves = vals["SQ_WAVES"]
+derived = {
+    "VALU instructions per wave": vals["SQ_INSTS_VALU"] / waves,
+    "VALUUtilization = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) (active lanes per VALU instruction)": vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_ACTIVE_INST_VALU"] * 64),
+    "VALUBusy (gfx94x formula) = SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); sums the issue windows of the ~4 resident waves, so it exceeds 1 when the VALU is saturated": vals["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (vals["GRBM_GUI_ACTIVE"] / 8),
+    "shader clock, GHz (GRBM_GUI_ACTIVE / 8 / kernel time)": vals["GRBM_GUI_ACTIVE"] / 8 / (kms * 1e-3) * 1e-9,
+    "VALU active share of wave cycles (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)": vals["SQ_ACTIVE_INST_VALU"] / wc,
+    "any-instruction active share of wave cycles": vals["SQ_ACTIVE_INST_ANY"] / wc,
+    "resident waves per SIMD (SQ_WAVE_CYCLES*4 / (1024 SIMDs * kernel cycles at the measured ~2.28 GHz))": wc * 4 / (1024 * kms * 1e-3 * 2.28e9),
+    "LDS bank-conflict share of LDS-array cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": vals["SQ_LDS_BANK_CONFLICT"] / max(vals["SQ_LDS_IDX_ACTIVE"], 1),
+    "issue-stall share (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": vals["SQ_WAIT_INST_ANY"] / wc,
+    "waitcnt/barrier share (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": vals["SQ_WAIT_ANY"] / wc,
+    "VALU wave-instruction issue interval per SIMD, ns (kernel time * 1024 SIMDs / SQ_INSTS_VALU)": kms * 1e6 * 1024 / vals["SQ_INSTS_VALU"],
+}
+lines += ["", "| derived | value |", "|---|---|"]
+for k, v in derived.items():
+    lines.append("| %s | %.4g |" % (k, v))
+lines += ["", "kernel_ms of the counted launch: %.2f; algorithmic roofline fraction of that run: %.3f" % (kms, bench["roofline"]["frac"])]
+open("profiles/%s_megakernel_counters.md" % tag, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
