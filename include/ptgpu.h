@@ -178,7 +178,8 @@ enum {
     PT_FN_SCHLICK = 5,     /* material.zig:120  in: cos,ri (2)                    out: prob (1)            */
     PT_FN_REFLECT = 6,     /* material.zig:59   in: d,n (6)                       out: r (3)               */
     PT_FN_LERP = 7,        /* illumination.zig:27 in: d,p0,p1 (9)                 out: err,rgb (4)         */
-    PT_FN_PHILOX = 8       /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
+    PT_FN_PHILOX = 8,      /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
+    PT_FN_SCENE_HIT_FILTERED = 9 /* scene.zig:96 as the megakernel evaluates it (LDS filter + exact pass): in/out as PT_FN_SCENE_HIT */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);

@@ -96,6 +96,118 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #define PT_ACC(idx, a, b)
 #endif
 
+// Scene.is_hit (scene.zig:96-110) for the 64 rays of a wave: conservative filter scan over the LDS
+// tile(s), then the reference's exact Sphere.is_hit (sphere.zig:63-103) on the survivors.  Shared by
+// the megakernel and by the PT_FN_SCENE_HIT_FILTERED debug kernel (tests compare it with the plain
+// exact scan).  All threads of the workgroup must call it together when MULTI_TILE (barriers).
+#ifdef PT_PHASE_TIMING
+#define PT_FLUSH_ACC(a, b) t_flush += (b) - (a)
+#else
+#define PT_FLUSH_ACC(a, b)
+#endif
+template <bool MULTI_TILE, class GeomOf>
+__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint32_t n_pad, float4 *s_filt, uint32_t *s_mask,
+                                                      uint32_t tid, GeomOf geom_of, V3 o, V3 d, float a, float t_min, float t_max,
+                                                      float &closest, int &hit, unsigned long long &n_cands,
+                                                      uint32_t &n_flush_iters, unsigned long long &t_flush) {
+    constexpr uint32_t TILE = (uint32_t)kTile;
+    (void)t_flush;
+    {
+        const float inv = rsqrtf(a);
+        const float hx = d.x * inv, hy = d.y * inv, hz = d.z * inv;
+        const float od = fmaf(o.z, hz, fmaf(o.y, hy, o.x * hx));
+        const float oo = fmaf(o.z, o.z, fmaf(o.y, o.y, o.x * o.x));
+        const float wx = 2.0f * fmaf(-od, hx, o.x);
+        const float wy = 2.0f * fmaf(-od, hy, o.y);
+        const float wz = 2.0f * fmaf(-od, hz, o.z);
+        const float E = fmaf(od, od, (kKeps - 1.0f) * oo);
+        // One bit per tested sphere, 32 tests per word: after the compare, VCC is shifted
+        // into the lane's word with a single v_addc (m = m + m + vcc) — no branch, no
+        // scalar work per test.  A word's first test ends up in its highest used bit.
+        uint32_t m = 0;    // word under construction
+        uint32_t S = 0;    // one bit per stored word of this tile: "word is non-zero"
+
+        for (uint32_t tile = 0; tile < n_pad; tile += TILE) {
+            const uint32_t tn = min(TILE, n_pad - tile);      // multiple of 2*kSub
+            const uint32_t nw = (tn + 31u) >> 5;              // words of this tile
+            const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
+            if (MULTI_TILE) {
+                __syncthreads();
+                for (uint32_t i = tid; i < tn; i += kBlock) s_filt[i] = g_filt[tile + i];
+                __syncthreads();
+            }
+            // Software-pipelined scan: the filter records of the next kSub spheres are
+            // fetched while the current kSub are tested; two register sets, ping-pong.
+            auto load = [&](float4 (&f)[kSub], uint32_t j0) {
+#pragma unroll
+                for (int k = 0; k < kSub; ++k) f[k] = s_filt[j0 + k];
+            };
+            auto test = [&](const float4 (&f)[kSub]) {
+#pragma unroll
+                for (int k = 0; k < kSub; ++k) {
+                    float q = f[k].x * hx;
+                    q = fmaf(f[k].y, hy, q);
+                    q = fmaf(f[k].z, hz, q);
+                    float s = fmaf(f[k].x, wx, E);
+                    s = fmaf(f[k].y, wy, s);
+                    s = fmaf(f[k].z, wz, s);
+                    const float F = fmaf(q, q, s);
+                    // candidate iff F >= T
+                    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f[k].w), "v"(F) : "vcc");
+                }
+            };
+            auto store_word = [&](uint32_t w, uint32_t tests_in_word) {
+                const uint32_t mv = (tests_in_word >= 32u) ? m : (m & ((1u << tests_in_word) - 1u));
+                s_mask[w * kBlock + tid] = mv;
+                S = S + S + (mv != 0u ? 1u : 0u);
+            };
+            float4 fa[kSub], fb[kSub];
+            load(fa, 0);
+            for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) {
+                load(fb, j0 + kSub);
+                test(fa);
+                if (j0 + 2 * kSub < tn) load(fa, j0 + 2 * kSub);
+                test(fb);
+                const uint32_t done = j0 + 2 * kSub;           // tests of this tile so far
+                if ((done & 31u) == 0u) store_word((done >> 5) - 1u, 32u);
+                else if (done == tn) store_word(nw - 1u, g_last);
+            }
+            // ---- exact Sphere.is_hit (sphere.zig:63-103) on the survivors, ascending sphere
+            // index, strict '<' (scene.zig:102): each lane walks its own words/bits; the
+            // wave iterates max-over-lanes(candidates) times.
+            PT_STAMP(tF0);
+            {
+                uint32_t mw = 0, wcur = 0, gcur = 32;
+                for (;;) {
+                    if (mw == 0u && S != 0u) {
+                        const uint32_t b = 31u - (uint32_t)__clz((int)S);
+                        S &= ~(1u << b);
+                        wcur = nw - 1u - b;
+                        gcur = (wcur == nw - 1u) ? g_last : 32u;
+                        mw = s_mask[wcur * kBlock + tid];
+                    }
+                    const bool has = mw != 0u;
+                    if (__ballot(has) == 0ull) break;
+                    n_flush_iters++;
+                    if (has) {
+                        const uint32_t b = 31u - (uint32_t)__clz((int)mw);
+                        mw &= ~(1u << b);
+                        const uint32_t j = tile + (wcur << 5) + (gcur - 1u - b);
+                        const float4 g = geom_of(j);
+                        n_cands++;
+                        float t;
+                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
+                            if (t < closest) { closest = t; hit = (int)j; }
+                        }
+                    }
+                }
+            }
+            PT_STAMP(tF1);
+            PT_FLUSH_ACC(tF0, tF1);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // the megakernel
 // ---------------------------------------------------------------------------
@@ -152,6 +264,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     rng.init(P.seed_lo, P.seed_hi);
     unsigned long long n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0;
     uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
+    unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
     unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -224,100 +337,8 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        {
-            const float inv = rsqrtf(a);
-            const float hx = d.x * inv, hy = d.y * inv, hz = d.z * inv;
-            const float od = fmaf(o.z, hz, fmaf(o.y, hy, o.x * hx));
-            const float oo = fmaf(o.z, o.z, fmaf(o.y, o.y, o.x * o.x));
-            const float wx = 2.0f * fmaf(-od, hx, o.x);
-            const float wy = 2.0f * fmaf(-od, hy, o.y);
-            const float wz = 2.0f * fmaf(-od, hz, o.z);
-            const float E = fmaf(od, od, (kKeps - 1.0f) * oo);
-            // One bit per tested sphere, 32 tests per word: after the compare, VCC is shifted
-            // into the lane's word with a single v_addc (m = m + m + vcc) — no branch, no
-            // scalar work per test.  A word's first test ends up in its highest used bit.
-            uint32_t m = 0;    // word under construction
-            uint32_t S = 0;    // one bit per stored word of this tile: "word is non-zero"
-
-            for (uint32_t tile = 0; tile < n_pad; tile += TILE) {
-                const uint32_t tn = min(TILE, n_pad - tile);      // multiple of 2*kSub
-                const uint32_t nw = (tn + 31u) >> 5;              // words of this tile
-                const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
-                if (MULTI_TILE) {
-                    __syncthreads();
-                    for (uint32_t i = tid; i < tn; i += kBlock) s_filt[i] = P.filt[tile + i];
-                    __syncthreads();
-                }
-                // Software-pipelined scan: the filter records of the next kSub spheres are
-                // fetched while the current kSub are tested; two register sets, ping-pong.
-                auto load = [&](float4 (&f)[kSub], uint32_t j0) {
-#pragma unroll
-                    for (int k = 0; k < kSub; ++k) f[k] = s_filt[j0 + k];
-                };
-                auto test = [&](const float4 (&f)[kSub]) {
-#pragma unroll
-                    for (int k = 0; k < kSub; ++k) {
-                        float q = f[k].x * hx;
-                        q = fmaf(f[k].y, hy, q);
-                        q = fmaf(f[k].z, hz, q);
-                        float s = fmaf(f[k].x, wx, E);
-                        s = fmaf(f[k].y, wy, s);
-                        s = fmaf(f[k].z, wz, s);
-                        const float F = fmaf(q, q, s);
-                        // candidate iff F >= T
-                        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f[k].w), "v"(F) : "vcc");
-                    }
-                };
-                auto store_word = [&](uint32_t w, uint32_t tests_in_word) {
-                    const uint32_t mv = (tests_in_word >= 32u) ? m : (m & ((1u << tests_in_word) - 1u));
-                    s_mask[w * kBlock + tid] = mv;
-                    S = S + S + (mv != 0u ? 1u : 0u);
-                };
-                float4 fa[kSub], fb[kSub];
-                load(fa, 0);
-                for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) {
-                    load(fb, j0 + kSub);
-                    test(fa);
-                    if (j0 + 2 * kSub < tn) load(fa, j0 + 2 * kSub);
-                    test(fb);
-                    const uint32_t done = j0 + 2 * kSub;           // tests of this tile so far
-                    if ((done & 31u) == 0u) store_word((done >> 5) - 1u, 32u);
-                    else if (done == tn) store_word(nw - 1u, g_last);
-                }
-                // ---- exact Sphere.is_hit (sphere.zig:63-103) on the survivors, ascending sphere
-                // index, strict '<' (scene.zig:102): each lane walks its own words/bits; the
-                // wave iterates max-over-lanes(candidates) times.
-                PT_STAMP(tF0);
-                {
-                    uint32_t mw = 0, wcur = 0, gcur = 32;
-                    for (;;) {
-                        if (mw == 0u && S != 0u) {
-                            const uint32_t b = 31u - (uint32_t)__clz((int)S);
-                            S &= ~(1u << b);
-                            wcur = nw - 1u - b;
-                            gcur = (wcur == nw - 1u) ? g_last : 32u;
-                            mw = s_mask[wcur * kBlock + tid];
-                        }
-                        const bool has = mw != 0u;
-                        if (__ballot(has) == 0ull) break;
-                        n_flush_iters++;
-                        if (has) {
-                            const uint32_t b = 31u - (uint32_t)__clz((int)mw);
-                            mw &= ~(1u << b);
-                            const uint32_t j = tile + (wcur << 5) + (gcur - 1u - b);
-                            const float4 g = geom_of(j);
-                            n_cands++;
-                            float t;
-                            if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
-                                if (t < closest) { closest = t; hit = (int)j; }
-                            }
-                        }
-                    }
-                }
-                PT_STAMP(tF1);
-                PT_ACC(2, tF0, tF1);
-            }
-        }
+        scene_is_hit_filtered<MULTI_TILE>(P.filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
+                                          n_cands, n_flush_iters, t_flush);
         if (alive) n_rays++;
         n_wave_steps++;
         PT_STAMP(tC0);
@@ -371,6 +392,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     if (lane == 0) {
         t_phase[4] = __builtin_amdgcn_s_memtime() - t_begin;
         atomicAdd(&P.counters[13], __builtin_amdgcn_s_memrealtime() - r_begin);
+        t_phase[2] = t_flush;
         for (int i = 0; i < 5; ++i) atomicAdd(&P.counters[8 + i], t_phase[i]);
     }
 #endif
@@ -534,6 +556,38 @@ __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t 
         const V3 nd = scatter((uint32_t)r[9], r[10], v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), v3(r[6], r[7], r[8]), ar);
         w[0] = nd.x; w[1] = nd.y; w[2] = nd.z; w[3] = (float)ar.n;
     }
+}
+
+// PT_FN_SCENE_HIT_FILTERED: the megakernel's own Scene.is_hit (LDS filter + exact pass) on caller
+// rays, one ray per thread, same output record as PT_FN_SCENE_HIT (the plain exact scan).
+template <bool MULTI_TILE>
+__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const float *in, float *out, uint32_t n, const float4 *g_filt,
+                                                                      const float4 *g_geom, uint32_t nspheres, float t_min, float t_max) {
+    __shared__ float4 s_filt[kTile];
+    __shared__ uint32_t s_mask[kMaskWords * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    const uint32_t n_pad = (nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    if (!MULTI_TILE) {
+        for (uint32_t k = tid; k < n_pad; k += kBlock) s_filt[k] = g_filt[k];
+        __syncthreads();
+    }
+    const bool live = i < n;
+    const float *r = in + (size_t)(live ? i : 0) * 6;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const float a = vlen2(d);
+    float closest = t_max;
+    int hit = -1;
+    unsigned long long n_cands = 0, t_flush = 0;
+    uint32_t n_flush_iters = 0;
+    auto geom_of = [&](uint32_t j) -> float4 { return g_geom[j]; };
+    scene_is_hit_filtered<MULTI_TILE>(g_filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
+                                      n_flush_iters, t_flush);
+    if (!live) return;
+    float *w = out + (size_t)i * 8;
+    V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+    if (hit >= 0) { const float4 g = g_geom[hit]; sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, nn); }
+    w[0] = (float)hit; w[1] = (hit >= 0) ? closest : 0.f; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
 }
 
 } // namespace
@@ -925,6 +979,7 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_SCATTER: in_stride = 27; out_stride = 4; break;
     case PT_FN_SPHERE_HIT: in_stride = 12; out_stride = 8; break;
     case PT_FN_SCENE_HIT: in_stride = 6; out_stride = 8; break;
+    case PT_FN_SCENE_HIT_FILTERED: in_stride = 6; out_stride = 8; break;
     case PT_FN_REFRACT: in_stride = 7; out_stride = 4; break;
     case PT_FN_SCHLICK: in_stride = 2; out_stride = 1; break;
     case PT_FN_REFLECT: in_stride = 6; out_stride = 3; break;
@@ -932,7 +987,7 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
     default: return PT_ERR_UNSUPPORTED;
     }
-    if (fn == PT_FN_SCENE_HIT && !ctx->d_geom) return PT_ERR_BAD_ARG;
+    if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
     if (fn == PT_FN_CAST_RAY && !ctx->have_camera) return PT_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *d_in = nullptr, *d_out = nullptr;
@@ -943,7 +998,15 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     e = hipMemcpy(d_in, in, in_stride * n * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         Cam cam = ctx->have_camera ? ctx->cam : Cam();
-        if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER)
+        if (fn == PT_FN_SCENE_HIT_FILTERED) {
+            const uint32_t blocks = (n + kBlock - 1) / kBlock;
+            if (ctx->n_pad > (uint32_t)kTile)
+                hipLaunchKernelGGL((pt_debug_scene_hit_filtered<true>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                                   (const float4 *)ctx->d_filt, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
+            else
+                hipLaunchKernelGGL((pt_debug_scene_hit_filtered<false>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                                   (const float4 *)ctx->d_filt, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
+        } else if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER)
             hipLaunchKernelGGL(pt_debug_eval_rng, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam);
         else
             hipLaunchKernelGGL(pt_debug_eval, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam,
