@@ -39,8 +39,11 @@ __device__ __forceinline__ V3 vunit(V3 a) {
 // std.rand.DefaultPrng (main.zig:100, renderers/ppm_image.zig:110, material.zig:15).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#ifndef PT_EXPERIMENT_PHILOX_ROUNDS // tools/build_variant.sh: timing experiments only (breaks parity)
+#define PT_EXPERIMENT_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PT_EXPERIMENT_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 product each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;

@@ -359,7 +359,9 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                     V3 p, n;
                     sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, n);
                     const V3 nd = scatter(kind, m.w, d, p, n, rng);
+#ifndef PT_EXPERIMENT_NO_STACK // tools/build_variant.sh timing experiment (breaks parity)
                     P.stack[(size_t)bounce * P.total_threads + gtid] = (uint32_t)hit;
+#endif
                     bounce++;
                     o = p; d = nd;
                 }
@@ -367,7 +369,11 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
                 ok = lerp_sky(d, P.blend_start, P.blend_stop, color); // illumination.zig:88
                 // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
                 for (uint32_t b = bounce; b > 0; --b) {
+#ifndef PT_EXPERIMENT_NO_STACK
                     const uint32_t id = P.stack[(size_t)(b - 1) * P.total_threads + gtid];
+#else
+                    const uint32_t id = b;
+#endif
                     if (kind_of(id) != 2u) {
                         const float4 m = mat_of(id);
                         color = vemul(color, v3(m.x, m.y, m.z));
