@@ -149,14 +149,18 @@ int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum
  * sum*(1/subpixels)*(1/rays_per_subsample), *max_px_value, truncating u8, the
  * 12-byte "%3d %3d %3d\n" record of render_targets/ppm_image.zig:93-103.
  * d_records receives (idx_stop-idx_start)*12 bytes (record of pixel idx at
- * (idx-idx_start)*12); either output may be NULL.  d_rgb8 receives 3 bytes/pixel. */
+ * (idx-idx_start)*12); either output may be NULL.  d_rgb8 receives 3 bytes/pixel.
+ * A colour above max_px_value (the reference asserts col <= 255 and its
+ * @floatToInt(u8) is undefined beyond) is written clamped to 255 and the call
+ * returns PT_ERR_VALUE_EXCEEDS_MAX after writing every record. */
 int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const float *d_rgb_sum,
                          uint8_t *d_records, uint8_t *d_rgb8, void *stream);
 
 /* Whole render() replacement on host buffers: traces [idx_start, idx_stop) and
  * writes the pixel records into slice[header_size + idx*px_size ..], exactly the
  * bytes render() writes (renderers/ppm_image.zig:81-82).  The caller writes the
- * header afterwards (main.zig:180-182).  px_size must be 12 (max_px_value 255). */
+ * header afterwards (main.zig:180-182).  px_size must be 12 (max_px_value 255).
+ * PT_ERR_VALUE_EXCEEDS_MAX as for ptgpu_resolve_device (records are written). */
 int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *slice, size_t slice_len,
                      uint32_t header_size, uint32_t px_size);
 

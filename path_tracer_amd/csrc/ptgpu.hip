@@ -950,7 +950,11 @@ extern "C" int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const 
                        (float)cfg->max_px_value, d_records, d_rgb8, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    return PT_OK;
+    // renderers/ppm_image.zig:75-77 asserts col <= 255 (and @floatToInt(u8) is undefined beyond it in
+    // ReleaseFast): such values are written clamped to 255 and reported
+    unsigned long long clamped = 0;
+    HIP_TRY(ctx, hipMemcpy(&clamped, ctx->d_counters + (CNT_N - 1), sizeof clamped, hipMemcpyDeviceToHost));
+    return clamped ? PT_ERR_VALUE_EXCEEDS_MAX : PT_OK;
 }
 
 extern "C" int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *slice, size_t slice_len, uint32_t header_size,
@@ -970,10 +974,10 @@ extern "C" int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *s
     rc = ensure(ctx, (void **)&ctx->d_rec, &ctx->rec_bytes, (size_t)npix * 12u);
     if (rc != PT_OK) return rc;
     rc = ptgpu_resolve_device(ctx, cfg, ctx->d_tmp, ctx->d_rec, nullptr, nullptr);
-    if (rc != PT_OK) return rc;
+    if (rc != PT_OK && rc != PT_ERR_VALUE_EXCEEDS_MAX) return rc;
     HIP_TRY(ctx, hipMemcpy(slice + header_size + (size_t)cfg->idx_start * px_size, ctx->d_rec, (size_t)npix * 12u, hipMemcpyDeviceToHost));
     ctx->stats = keep;
-    return PT_OK;
+    return rc; // PT_ERR_VALUE_EXCEEDS_MAX: records written with the offending values clamped to 255
 }
 
 extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n, float t_min, float t_max) {

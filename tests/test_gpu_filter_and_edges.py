@@ -183,3 +183,23 @@ def test_bad_configs_are_rejected(gpu):
     with pytest.raises(PtGpuError) as e:   # NoSpaceLeft: slice too small
         gpu.render_ppm(host.make_pt_config(img, rt), np.zeros(100, dtype=np.uint8), img.header_size, img.px_size)
     assert e.value.status == _lib.PT_ERR_NO_SPACE
+
+
+def test_colour_above_max_is_clamped_and_reported(gpu):
+    """renderers/ppm_image.zig:75-77 asserts col <= 255: a sky brighter than 1.0 is written as 255 and the
+    call returns ValueExceedsMaxValue after writing every record."""
+    from path_tracer_amd import _lib, host
+    from path_tracer_amd._lib import PtGpuError
+    scene = host.Scene().setupScene(0, 18)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(host.Camera.preset(18).pod)
+    img = host.Image(32)
+    rt = host.RayTracerConfig(subpixels=1, rays_per_subsample=1)
+    cfg = host.make_pt_config(img, rt, deterministic=True)
+    cfg.blend_start[0] = cfg.blend_stop[0] = 3.0      # red sky = 3.0 -> 765 > 255
+    buf = np.zeros(img.size, dtype=np.uint8)
+    with pytest.raises(PtGpuError) as e:
+        gpu.render_ppm(cfg, buf, img.header_size, img.px_size)
+    assert e.value.status == _lib.PT_ERR_VALUE_EXCEEDS_MAX
+    first = bytes(buf[img.header_size:img.header_size + 12])
+    assert first[:3] == b"255" and first[11:12] == b"\n"        # top-left pixel is sky
