@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--seed", type=int, default=456)
     ap.add_argument("--chunk", type=int, default=64, help="samples per GPU work item")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="development only: run the N>1 plumbing on ONE GPU (all ranks on cuda:0, gloo all_reduce "
+                         "instead of the RCCL reduce); the JSON line is marked and is not a benchmark result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,9 +81,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from path_tracer_amd import host
     from path_tracer_amd.distributed import gpu_render_into, render_sum_distributed
@@ -98,7 +106,8 @@ def main():
     frame = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device="cuda")
 
     def step():
-        render_sum_distributed(render_into, img, rt, args.seed, split="samples", chunk=args.chunk, frame=frame)
+        render_sum_distributed(render_into, img, rt, args.seed, split="samples", chunk=args.chunk, frame=frame,
+                               everywhere=args.rehearse_gloo)  # gloo has no CUDA reduce, only all_reduce
         return gpu.stats()
 
     def fence():
@@ -157,6 +166,8 @@ def main():
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d); algorithmic FLOPs = "
                                  "18/ray-sphere test + 60/ray + 40/path over the device-counted rays of rank 0's launch"},
         }
+        if args.rehearse_gloo:
+            out["rehearsal"] = "all ranks on ONE GPU over gloo: plumbing check only, not a benchmark result"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
         print(json.dumps(out), flush=True)

@@ -47,11 +47,11 @@ def plan(img, rt, seed, world, rank, split="samples", chunk=0, deterministic=Fal
 
 
 def render_sum_distributed(render_into, img, rt, seed, split="samples", chunk=0, deterministic=False, tile_pixels=256,
-                           device="cuda", group=None, frame=None):
+                           device="cuda", group=None, frame=None, everywhere=False):
     """Every rank renders its share into a zeroed full-frame buffer and the buffers are summed
     on rank 0 (dist.reduce, RCCL for CUDA tensors).  `render_into(cfg, frame_tensor)` is the
     single-GPU render (GpuContext.render_sum_device on frame.data_ptr()).  Returns the frame
-    tensor (complete on rank 0 only)."""
+    tensor (complete on rank 0 only; on every rank with everywhere=True, which uses all_reduce)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if frame is None:
@@ -62,7 +62,10 @@ def render_sum_distributed(render_into, img, rt, seed, split="samples", chunk=0,
     if cfg is not None:
         render_into(cfg, frame)
     if world > 1:
-        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if everywhere:
+            dist.all_reduce(frame, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, group=group)
     return frame
 
 
