@@ -16,4 +16,6 @@ pass() { # name, counters...
 pass pmc_valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY
 pass pmc_lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM
 pass pmc_grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pass pmc_fetch FETCH_SIZE
+pass pmc_write WRITE_SIZE
 ls -R $out | head -40

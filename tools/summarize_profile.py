@@ -6,7 +6,9 @@ os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), "profiles/%s_bench_kernel_stats.csv" % tag)
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), "profiles/%s_bench_under_rocprof.json" % tag)
 vals = {}
-for name in ("pmc_valu", "pmc_lds", "pmc_grbm"):
+for name in ("pmc_valu", "pmc_lds", "pmc_grbm", "pmc_fetch", "pmc_write"):
+    if not os.path.exists(os.path.join(src, name, "p_counter_collection.csv")):
+        continue
     with open(os.path.join(src, name, "p_counter_collection.csv")) as f:
         for row in csv.DictReader(f):
             if "megakernel" not in row["Kernel_Name"]:
@@ -33,6 +35,12 @@ derived = {
     "waitcnt/barrier share (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": vals["SQ_WAIT_ANY"] / wc,
     "VALU wave-instruction issue interval per SIMD, ns (kernel time * 1024 SIMDs / SQ_INSTS_VALU)": kms * 1e6 * 1024 / vals["SQ_INSTS_VALU"],
 }
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    # rocprofv3 derived metrics, in KB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
+    # (double it for wide coalesced reads); other widths are uncalibrated, so both figures are orders of magnitude
+    derived["HBM-side read KB per launch (FETCH_SIZE as reported; x2 for the gfx950 correction)"] = vals["FETCH_SIZE"]
+    derived["HBM-side write KB per launch (WRITE_SIZE)"] = vals["WRITE_SIZE"]
+    derived["HBM-side GB/s of the launch ((2*FETCH_SIZE + WRITE_SIZE) KB / kernel time) against ~8000 GB/s peak"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / (kms * 1e-3) * 1e-9
 lines += ["", "| derived | value |", "|---|---|"]
 for k, v in derived.items():
     lines.append("| %s | %.4g |" % (k, v))
