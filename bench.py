@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="rays_per_subsample per GPU (x4 subpixels = paths/pixel)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=456)
-    ap.add_argument("--chunk", type=int, default=64, help="samples per GPU work item")
+    ap.add_argument("--chunk", type=int, default=16, help="samples per GPU work item")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: run the N>1 plumbing on ONE GPU (all ranks on cuda:0, gloo all_reduce "

@@ -43,6 +43,7 @@ namespace {
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kTile = 512;           // spheres per tile: 16 candidate-mask words per lane (and 8 KiB of float4 when LDS-fed)
 constexpr int kMaskWords = kTile / 32;
+constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue atomic
 constexpr int kSub = 4;              // spheres per software-pipeline stage (one s_load_dwordx16)
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
 
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
     const uint32_t total_items = P.npix * P.nchunks;
+    uint32_t pool_next = 0, pool_end = 0; // wave-uniform: items [pool_next, pool_end) are reserved for this wave
 
     for (;;) {
         // ---- phase A: refill lanes whose path has ended -------------------------
@@ -286,13 +288,23 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
             const bool want = alive && need_path && sample == s_end;
             const unsigned long long m = __ballot(want);
             if (m != 0ull) {
-                uint32_t base = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if ((int)lane == leader)
-                    base = (uint32_t)atomicAdd(&P.counters[CNT_QUEUE], (unsigned long long)__popcll(m));
-                base = __shfl(base, leader, 64);
+                // The wave draws items from a pool it reserved earlier and reserves kItemBatch more
+                // with ONE atomic only when the pool cannot serve every requesting lane: the
+                // atomic's round trip is paid once per ~64 items, not once per ray step.
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                const uint32_t avail = pool_end - pool_next;
+                uint32_t fresh = 0;
+                if (cnt > avail) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    if ((int)lane == leader) fresh = (uint32_t)atomicAdd(&P.counters[CNT_QUEUE], (unsigned long long)kItemBatch);
+                    fresh = __shfl(fresh, leader, 64);
+                }
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t item_ = (rank < avail) ? pool_next + rank : fresh + (rank - avail);
+                if (cnt > avail) { pool_next = fresh + (cnt - avail); pool_end = fresh + kItemBatch; }
+                else pool_next += cnt;
                 if (want) {
-                    const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint32_t item = item_;
                     if (item < total_items) {
                         const uint32_t k = item / P.npix;
                         const uint32_t po = item - k * P.npix;
@@ -818,7 +830,7 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (npix == 0 || s1 == s0) return PT_OK;
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
-    if ((uint64_t)npix * nchunks > 0xfffffff0ull) return PT_ERR_BAD_ARG;
+    if ((uint64_t)npix * nchunks > 0xf0000000ull) return PT_ERR_BAD_ARG; // u32 item ids incl. the waves' last (overshooting) reservations
 
     const uint32_t grid = (uint32_t)(ctx->compute_units * ctx->blocks_per_cu);
     const uint32_t total_threads = grid * kBlock;
