@@ -41,10 +41,25 @@ using namespace ptdev;
 namespace {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
-constexpr int kTile = 512;           // spheres per tile: 16 candidate-mask words per lane (and 8 KiB of float4 when LDS-fed)
-constexpr int kMaskWords = kTile / 32;
+constexpr int kTile = 512;           // spheres per LDS staging tile (8 KiB of float4 filter records)
+#ifndef PT_MASK_TILE
+#define PT_MASK_TILE 256
+#endif
+// Spheres scanned between two exact passes (= 32 x the candidate words a lane keeps in LDS).  Single-tile
+// scenes use 256 (27 KiB of LDS per workgroup with the material tables: 5 workgroups per CU); multi-tile
+// scenes have no tables in LDS and take the whole staging tile (fewer exact passes per ray step).
+constexpr int kMaskTile = PT_MASK_TILE;
+constexpr int mask_tile(bool multi_tile) { return multi_tile ? kTile : kMaskTile; }
+constexpr int kPad = 8;              // the filter table is padded to a multiple of kPad records
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 5
+#endif
 constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue atomic
-constexpr int kSub = 4;              // spheres per software-pipeline stage (one s_load_dwordx16)
+#ifndef PT_SUB
+#define PT_SUB 4
+#endif
+constexpr int kSub = PT_SUB;         // spheres per software-pipeline stage (two register sets of kSub records, ping-pong)
+static_assert(kPad % (2 * kSub) == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
 
 enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 16 };
@@ -63,7 +78,7 @@ struct KParams {
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
     uint32_t nspheres;
     uint32_t total_threads;
-    const float4 *filt; // (cx, cy, cz, threshold) padded to a multiple of 2*kSub
+    const float4 *filt; // (cx, cy, cz, threshold) padded to a multiple of kPad
     const float4 *geom; // (cx, cy, cz, radius)
     const float4 *mat;  // (albedo r, g, b, param)
     const uint32_t *kind;
@@ -107,9 +122,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #define PT_FLUSH_ACC(a, b)
 #endif
 template <bool MULTI_TILE, class GeomOf>
-__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint32_t n_pad, float4 *s_filt, uint32_t *s_mask,
+__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
                                                       uint32_t tid, GeomOf geom_of, V3 o, V3 d, float a, float t_min, float t_max,
-                                                      float &closest, int &hit, unsigned long long &n_cands,
+                                                      float &closest, int &hit, uint32_t &n_cands,
                                                       uint32_t &n_flush_iters, unsigned long long &t_flush) {
     constexpr uint32_t TILE = (uint32_t)kTile;
     (void)t_flush;
@@ -128,15 +143,21 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
         uint32_t m = 0;    // word under construction
         uint32_t S = 0;    // one bit per stored word of this tile: "word is non-zero"
 
-        for (uint32_t tile = 0; tile < n_pad; tile += TILE) {
-            const uint32_t tn = min(TILE, n_pad - tile);      // multiple of 2*kSub
-            const uint32_t nw = (tn + 31u) >> 5;              // words of this tile
-            const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
+        for (uint32_t tile0 = 0; tile0 < n_pad; tile0 += TILE) {
+            const uint32_t tile_n = min(TILE, n_pad - tile0);
             if (MULTI_TILE) {
                 __syncthreads();
-                for (uint32_t i = tid; i < tn; i += kBlock) s_filt[i] = g_filt[tile + i];
+                for (uint32_t i = tid; i < tile_n; i += kBlock) s_filt_all[i] = g_filt[tile0 + i];
                 __syncthreads();
             }
+          constexpr uint32_t MASK_TILE = (uint32_t)mask_tile(MULTI_TILE);
+          for (uint32_t grp = 0; grp < tile_n; grp += MASK_TILE) { // scan MASK_TILE spheres, then the exact pass
+            const uint32_t tile = tile0 + grp;                // first sphere of this group
+            const float4 *s_filt = s_filt_all + grp;
+            const uint32_t tn = min(MASK_TILE, tile_n - grp); // multiple of kPad
+            const uint32_t nw = (tn + 31u) >> 5;              // words of this group
+            const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
+            m = 0; S = 0;
             // Software-pipelined scan: the filter records of the next kSub spheres are
             // fetched while the current kSub are tested; two register sets, ping-pong.
             auto load = [&](float4 (&f)[kSub], uint32_t j0) {
@@ -205,6 +226,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
             }
             PT_STAMP(tF1);
             PT_FLUSH_ACC(tF0, tF1);
+          }
         }
     }
 }
@@ -220,10 +242,10 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
 // was measured 15 % slower on MI355X — 16 B per wave per test saturates the scalar cache, which
 // several CUs share, long before LDS.
 template <bool DET, bool MULTI_TILE>
-__global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
+__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
     constexpr uint32_t TILE = (uint32_t)kTile; // spheres per LDS staging tile = per candidate-mask tile
     __shared__ float4 s_filt[kTile];                 // (cx, cy, cz, T) filter records of the current tile
-    __shared__ uint32_t s_mask[kMaskWords * kBlock]; // candidate bit words, word-major (conflict-free)
+    __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
     __shared__ float s_radius[MULTI_TILE ? 1 : kTile];
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * kBlock + tid;
 
-    const uint32_t n_pad = (P.nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    const uint32_t n_pad = (P.nspheres + kPad - 1) / kPad * kPad;
     if (!MULTI_TILE) {
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
         for (uint32_t i = tid; i < P.nspheres; i += kBlock) {
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     uint32_t bounce = 0;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
-    unsigned long long n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0;
+    uint32_t n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0; // per-lane counts (widened when the wave sums them)
     uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
     unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
@@ -415,15 +437,13 @@ __global__ __launch_bounds__(kBlock, 4) void pt_megakernel(const KParams P) {
     }
 #endif
     // ---- statistics ---------------------------------------------------------------
-    n_rays = wave_sum_u64(n_rays);
-    n_cands = wave_sum_u64(n_cands);
-    n_paths = wave_sum_u64(n_paths);
-    n_not_unit = wave_sum_u64(n_not_unit);
+    const unsigned long long w_rays = wave_sum_u64(n_rays), w_cands = wave_sum_u64(n_cands), w_paths = wave_sum_u64(n_paths),
+                             w_not_unit = wave_sum_u64(n_not_unit);
     if (lane == 0) {
-        atomicAdd(&P.counters[CNT_RAYS], n_rays);
-        atomicAdd(&P.counters[CNT_CANDS], n_cands);
-        atomicAdd(&P.counters[CNT_PATHS], n_paths);
-        if (n_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], n_not_unit);
+        atomicAdd(&P.counters[CNT_RAYS], w_rays);
+        atomicAdd(&P.counters[CNT_CANDS], w_cands);
+        atomicAdd(&P.counters[CNT_PATHS], w_paths);
+        if (w_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], w_not_unit);
         atomicAdd(&P.counters[CNT_WAVE_STEPS], (unsigned long long)n_wave_steps);
         atomicAdd(&P.counters[CNT_FLUSH_ITERS], (unsigned long long)n_flush_iters);
     }
@@ -582,10 +602,10 @@ template <bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const float *in, float *out, uint32_t n, const float4 *g_filt,
                                                                       const float4 *g_geom, uint32_t nspheres, float t_min, float t_max) {
     __shared__ float4 s_filt[kTile];
-    __shared__ uint32_t s_mask[kMaskWords * kBlock];
+    __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
-    const uint32_t n_pad = (nspheres + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    const uint32_t n_pad = (nspheres + kPad - 1) / kPad * kPad;
     if (!MULTI_TILE) {
         for (uint32_t k = tid; k < n_pad; k += kBlock) s_filt[k] = g_filt[k];
         __syncthreads();
@@ -596,8 +616,8 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
     const float a = vlen2(d);
     float closest = t_max;
     int hit = -1;
-    unsigned long long n_cands = 0, t_flush = 0;
-    uint32_t n_flush_iters = 0;
+    unsigned long long t_flush = 0;
+    uint32_t n_cands = 0, n_flush_iters = 0;
     auto geom_of = [&](uint32_t j) -> float4 { return g_geom[j]; };
     scene_is_hit_filtered<MULTI_TILE>(g_filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
                                       n_flush_iters, t_flush);
@@ -630,7 +650,7 @@ struct ptgpu_ctx {
     uint8_t *d_rec = nullptr; size_t rec_bytes = 0;  // scratch records for ptgpu_render_ppm
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
     pt_stats stats;
 };
 
@@ -746,7 +766,7 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     for (uint32_t i = 0; i < n; ++i)
         if (spheres[i].kind > PT_DIELECTRIC) return PT_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t n_pad = (n + 2 * kSub - 1) / (2 * kSub) * (2 * kSub);
+    const uint32_t n_pad = (n + kPad - 1) / kPad * kPad;
     std::vector<float4> filt(n_pad), geom(n), mat(n);
     std::vector<uint32_t> kind(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -832,7 +852,20 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
     if ((uint64_t)npix * nchunks > 0xf0000000ull) return PT_ERR_BAD_ARG; // u32 item ids incl. the waves' last (overshooting) reservations
 
-    const uint32_t grid = (uint32_t)(ctx->compute_units * ctx->blocks_per_cu);
+    const bool multi = ctx->n_pad > (uint32_t)kTile;
+    const bool det = cfg->mode == 1;
+    // persistent grid: as many workgroups per CU as the kernel variant can keep resident
+    int resident = 0;
+    {
+        hipError_t oe;
+        if (det) oe = multi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<true, true>, kBlock, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<true, false>, kBlock, 0);
+        else oe = multi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<false, true>, kBlock, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<false, false>, kBlock, 0);
+        if (oe != hipSuccess || resident <= 0) resident = 1;
+    }
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : resident;
+    const uint32_t grid = (uint32_t)(ctx->compute_units * bpc);
     const uint32_t total_threads = grid * kBlock;
 
     float *part = nullptr;
@@ -866,8 +899,6 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    const bool multi = ctx->n_pad > (uint32_t)kTile;
-    const bool det = cfg->mode == 1;
     if (det) {
         if (multi) hipLaunchKernelGGL((pt_megakernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, P);
         else hipLaunchKernelGGL((pt_megakernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, P);
