@@ -58,8 +58,9 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 #ifndef PT_SUB
 #define PT_SUB 4
 #endif
-constexpr int kSub = PT_SUB;         // spheres per software-pipeline stage (two register sets of kSub records, ping-pong)
-static_assert(kPad % (2 * kSub) == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
+
+constexpr int kSub = PT_SUB;         // filter records held in registers ahead of their tests (software pipeline depth)
+static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
 
 enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 16 };
@@ -158,39 +159,32 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
             const uint32_t nw = (tn + 31u) >> 5;              // words of this group
             const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
             m = 0; S = 0;
-            // Software-pipelined scan: the filter records of the next kSub spheres are
-            // fetched while the current kSub are tested; two register sets, ping-pong.
-            auto load = [&](float4 (&f)[kSub], uint32_t j0) {
-#pragma unroll
-                for (int k = 0; k < kSub; ++k) f[k] = s_filt[j0 + k];
-            };
-            auto test = [&](const float4 (&f)[kSub]) {
-#pragma unroll
-                for (int k = 0; k < kSub; ++k) {
-                    float q = f[k].x * hx;
-                    q = fmaf(f[k].y, hy, q);
-                    q = fmaf(f[k].z, hz, q);
-                    float s = fmaf(f[k].x, wx, E);
-                    s = fmaf(f[k].y, wy, s);
-                    s = fmaf(f[k].z, wz, s);
-                    const float F = fmaf(q, q, s);
-                    // candidate iff F >= T
-                    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f[k].w), "v"(F) : "vcc");
-                }
-            };
             auto store_word = [&](uint32_t w, uint32_t tests_in_word) {
                 const uint32_t mv = (tests_in_word >= 32u) ? m : (m & ((1u << tests_in_word) - 1u));
                 s_mask[w * kBlock + tid] = mv;
                 S = S + S + (mv != 0u ? 1u : 0u);
             };
-            float4 fa[kSub], fb[kSub];
-            load(fa, 0);
-            for (uint32_t j0 = 0; j0 < tn; j0 += 2 * kSub) {
-                load(fb, j0 + kSub);
-                test(fa);
-                if (j0 + 2 * kSub < tn) load(fa, j0 + 2 * kSub);
-                test(fb);
-                const uint32_t done = j0 + 2 * kSub;           // tests of this tile so far
+            // Software-pipelined scan: kSub records in registers, refilled one by one — as soon as
+            // a record has been tested its registers take the record kSub places ahead (the LDS
+            // arrays carry kSub records of padding, so the last refills read unused slots).
+            float4 fr[kSub];
+#pragma unroll
+            for (int k = 0; k < kSub; ++k) fr[k] = s_filt[k];
+            for (uint32_t j0 = 0; j0 < tn; j0 += kPad) {
+#pragma unroll
+                for (int k = 0; k < kPad; ++k) {
+                    float4 &f = fr[k % kSub];
+                    float q = f.x * hx;
+                    q = fmaf(f.y, hy, q);
+                    q = fmaf(f.z, hz, q);
+                    float s = fmaf(f.x, wx, E);
+                    s = fmaf(f.y, wy, s);
+                    s = fmaf(f.z, wz, s);
+                    const float F = fmaf(q, q, s);
+                    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.w), "v"(F) : "vcc");
+                    f = s_filt[j0 + (uint32_t)k + (uint32_t)kSub];
+                }
+                const uint32_t done = j0 + kPad;
                 if ((done & 31u) == 0u) store_word((done >> 5) - 1u, 32u);
                 else if (done == tn) store_word(nw - 1u, g_last);
             }
@@ -243,8 +237,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
 // several CUs share, long before LDS.
 template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
-    constexpr uint32_t TILE = (uint32_t)kTile; // spheres per LDS staging tile = per candidate-mask tile
-    __shared__ float4 s_filt[kTile];                 // (cx, cy, cz, T) filter records of the current tile
+    __shared__ float4 s_filt[kTile + kSub];                 // (cx, cy, cz, T) filter records of the current tile
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
@@ -601,7 +594,7 @@ __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t 
 template <bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const float *in, float *out, uint32_t n, const float4 *g_filt,
                                                                       const float4 *g_geom, uint32_t nspheres, float t_min, float t_max) {
-    __shared__ float4 s_filt[kTile];
+    __shared__ float4 s_filt[kTile + kSub];
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
