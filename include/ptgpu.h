@@ -103,8 +103,19 @@ typedef struct pt_config {
     uint32_t max_px_value;                  /* Image.max_px_value (255)             */
     uint32_t tile_pixels;                   /* tile split: pixels per tile, 0 = off */
     uint32_t tile_count, tile_index;        /* tile t of the range belongs to owner t % tile_count */
-    uint32_t reserved;                      /* must be 0                            */
+    uint32_t illumination;                  /* PT_ILLUM_*: which illumination.zig function colours a sample */
 } pt_config;
+
+/* The reference has three per-sample colour functions; render() calls radiance and keeps the
+ * other two as commented-out alternatives (renderers/ppm_image.zig:64-66).  The first-hit ones
+ * trace one ray per sample and are cheap deterministic views for regression tests. */
+enum {
+    PT_ILLUM_RADIANCE = 0, /* illumination.zig:76-90  radiance (the path tracer)                      */
+    PT_ILLUM_NORMAL = 1,   /* illumination.zig:42-51  colorNormal: (unit(p - (0,0,-1)) + 1) * 0.5 (sic:
+                              the centre is the constant (0,0,-1), not the hit sphere's) or sky lerp  */
+    PT_ILLUM_ALBEDO = 2    /* illumination.zig:60-73  colorAlbedo: albedo of the first hit ((1,1,1) for
+                              a dielectric) or sky lerp                                                */
+};
 
 /* Counters of the last render on a context. */
 typedef struct pt_stats {

@@ -33,7 +33,7 @@ class Config(C.Structure):
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
                 ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
                 ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("illumination", C.c_uint32)]
 
 
 class Image(C.Structure):
@@ -185,7 +185,7 @@ def image_new(width, aspect=ASPECT_16_9, max_px_value=255):
 
 def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed=0, t_min=0.1, t_max=1000.0,
                 idx_start=0, idx_stop=None, sample_start=0, sample_stop=0, chunk=0, tile_pixels=0, tile_count=1,
-                tile_index=0):
+                tile_index=0, illumination=0):
     """RayTracerConfig as main.zig:85-91 sets it, plus the work range."""
     cfg = Config()
     cfg.width, cfg.height = img.width, img.height
@@ -199,6 +199,7 @@ def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed
     cfg.sample_start, cfg.sample_stop, cfg.chunk = sample_start, sample_stop, chunk
     cfg.max_px_value = img.max_px_value
     cfg.tile_pixels, cfg.tile_count, cfg.tile_index = tile_pixels, tile_count, tile_index
+    cfg.illumination = illumination
     return cfg
 
 

@@ -366,6 +366,35 @@ static int radiance(trace_ctx *tc, rng_t *r, ray_t ray, uint32_t num_rebounds, v
     return rc;
 }
 
+/* illumination.zig:42-51.  Sic: the "normal" is taken about the constant centre (0,0,-1). */
+static int color_normal(trace_ctx *tc, ray_t ray, vec3 *out) {
+    hit_t hit;
+    tc->rays++;
+    if (scene_is_hit(tc->sp, tc->n, ray, tc->t_min, tc->t_max, &hit)) {
+        const vec3 p = vadd(ray.origin, vmul(ray.direction, hit.t)); /* ray.zig:18 pointAt */
+        const vec3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
+        *out = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
+        return ORC_OK;
+    }
+    const int rc = lerp(ray.direction, tc->blend_start, tc->blend_stop, out);
+    if (rc != ORC_OK) tc->not_unit++;
+    return rc;
+}
+
+/* illumination.zig:60-73 */
+static int color_albedo(trace_ctx *tc, ray_t ray, vec3 *out) {
+    hit_t hit;
+    tc->rays++;
+    if (scene_is_hit(tc->sp, tc->n, ray, tc->t_min, tc->t_max, &hit)) {
+        const orc_sphere *m = &tc->sp[hit.index];
+        *out = (m->kind == 2) ? v3(1.0f, 1.0f, 1.0f) : v3(m->ar, m->ag, m->ab);
+        return ORC_OK;
+    }
+    const int rc = lerp(ray.direction, tc->blend_start, tc->blend_stop, out);
+    if (rc != ORC_OK) tc->not_unit++;
+    return rc;
+}
+
 /* The GPU kernel's shape of the same function: iterative bounce loop that records
  * the hit sphere per bounce, then applies the attenuations innermost-first.  Must
  * equal radiance() bit for bit (tests/test_oracle_kats.py::test_iterative_equals_recursive). */
@@ -416,6 +445,8 @@ static int trace_sample(trace_ctx *tc, const orc_camera *cam, const orc_config *
     const float u = ((float)i_col + rng_float(r_cam)) / (float)cfg->width;
     const float v = ((float)(cfg->height - i_row + 1) + rng_float(r_cam)) / (float)cfg->height; /* sic: +1 */
     const ray_t ray = cast_ray(cam, u, v, r_cam);
+    if (cfg->illumination == 1) return color_normal(tc, ray, out); /* renderers/ppm_image.zig:64 */
+    if (cfg->illumination == 2) return color_albedo(tc, ray, out); /* renderers/ppm_image.zig:65 */
     return iterative ? radiance_iterative(tc, r_mat, ray, cfg->rebounds, out)
                      : radiance(tc, r_mat, ray, cfg->rebounds, out);
 }

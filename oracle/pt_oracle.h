@@ -54,7 +54,8 @@ typedef struct orc_config {
     uint32_t sample_start, sample_stop;
     uint32_t chunk;
     uint32_t max_px_value;
-    uint32_t tile_pixels, tile_count, tile_index, reserved; /* interleaved tile ownership (multi-GPU split) */
+    uint32_t tile_pixels, tile_count, tile_index; /* interleaved tile ownership (multi-GPU split) */
+    uint32_t illumination; /* 0 radiance (illumination.zig:76), 1 colorNormal (:42), 2 colorAlbedo (:60) */
 } orc_config;
 
 typedef struct orc_image {

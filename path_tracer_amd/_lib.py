@@ -23,6 +23,7 @@ PT_ERR_NO_SPACE = -8
 PT_ERR_UNSUPPORTED = -9
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
+PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
 
 (PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
  PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED) = range(10)
@@ -52,7 +53,7 @@ class pt_config(C.Structure):
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
                 ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
                 ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("illumination", C.c_uint32)]
 
 
 class pt_stats(C.Structure):

@@ -71,6 +71,7 @@ struct KParams {
     float t_min, t_max;
     uint32_t width, height;
     uint32_t rebounds;
+    uint32_t illum;                 // PT_ILLUM_*
     uint32_t seed_lo, seed_hi;
     uint32_t idx_start, idx_stop;   // pixel range
     uint32_t npix;                  // pixel slots this launch owns (all of the range, or this owner's tiles)
@@ -377,7 +378,18 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             V3 color = v3(0.f, 0.f, 0.f);
             bool ok = true;
             if (hit >= 0) {
-                if (bounce == P.rebounds) {
+                if (P.illum != PT_ILLUM_RADIANCE) {
+                    // first-hit colour functions (renderers/ppm_image.zig:64-65)
+                    if (P.illum == PT_ILLUM_NORMAL) { // illumination.zig:45-47; sic: about the constant centre (0,0,-1)
+                        const V3 p = vadd(o, vmul(d, closest));
+                        const V3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
+                        color = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
+                    } else {                          // illumination.zig:65-69
+                        const float4 m = mat_of((uint32_t)hit);
+                        color = (kind_of((uint32_t)hit) == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
+                    }
+                    done = true;
+                } else if (bounce == P.rebounds) {
                     done = true; // illumination.zig:80-81: black
                 } else {
                     const float4 g = geom_of((uint32_t)hit);
@@ -812,7 +824,7 @@ static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, u
     const uint64_t np = (uint64_t)cfg->width * cfg->height;
     if (np > 0x7fffffffull / 3) return PT_ERR_BAD_ARG;
     if (cfg->idx_start > cfg->idx_stop || cfg->idx_stop > np) return PT_ERR_BAD_ARG;
-    if (cfg->mode > 1 || cfg->reserved != 0) return PT_ERR_BAD_ARG;
+    if (cfg->mode > 1 || cfg->illumination > PT_ILLUM_ALBEDO) return PT_ERR_BAD_ARG;
     if (cfg->tile_pixels != 0 &&
         (cfg->tile_count == 0 || cfg->tile_index >= cfg->tile_count || cfg->idx_start % cfg->tile_pixels != 0))
         return PT_ERR_BAD_ARG;
@@ -880,6 +892,7 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     P.t_min = cfg->t_min; P.t_max = cfg->t_max;
     P.width = cfg->width; P.height = cfg->height;
     P.rebounds = cfg->rebounds;
+    P.illum = cfg->illumination;
     P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
     P.idx_start = cfg->idx_start; P.idx_stop = cfg->idx_stop; P.npix = npix;
     P.tile_pixels = cfg->tile_pixels; P.tile_count = cfg->tile_count; P.tile_index = cfg->tile_index;

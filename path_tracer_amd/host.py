@@ -191,7 +191,7 @@ def filepath(num_scene, cfg, img, seed):
 
 
 def make_pt_config(img, rt, seed=0, istart=0, istop=None, deterministic=False, sample_start=0, sample_stop=0, chunk=0,
-                   tile_pixels=0, tile_count=1, tile_index=0):
+                   tile_pixels=0, tile_count=1, tile_index=0, illumination=0):
     c = pt_config()
     c.width, c.height = img.width, img.height
     c.subpixels, c.rays_per_subsample, c.rebounds = rt.subpixels, rt.rays_per_subsample, rt.rebounds
@@ -205,6 +205,7 @@ def make_pt_config(img, rt, seed=0, istart=0, istop=None, deterministic=False, s
     c.sample_start, c.sample_stop, c.chunk = int(sample_start), int(sample_stop), int(chunk)
     c.max_px_value = img.max_px_value
     c.tile_pixels, c.tile_count, c.tile_index = int(tile_pixels), int(tile_count), int(tile_index)
+    c.illumination = int(illumination)
     return c
 
 

@@ -271,6 +271,7 @@ int render(const Config &cfg) {
     c.blend_stop[0] = img.blend_stop.x; c.blend_stop[1] = img.blend_stop.y; c.blend_stop[2] = img.blend_stop.z;
     c.idx_start = (uint32_t)cfg.istart; c.idx_stop = (uint32_t)cfg.istop;
     c.chunk = cfg.chunk;
+    c.illumination = cfg.illumination;
     c.max_px_value = (uint32_t)img.max_px_value;
     return ptgpu_render_ppm(cfg.gpu, &c, cfg.slice, cfg.slice_len, (uint32_t)img.header_size, (uint32_t)img.px_size);
 }

@@ -130,6 +130,7 @@ struct Config {
     const Scene *scene;
     bool deterministic = false;
     uint32_t chunk = 0; // samples per GPU work item (0: one sequential sum per pixel, as the reference)
+    uint32_t illumination = PT_ILLUM_RADIANCE; // renderers/ppm_image.zig:64-66: radiance | colorNormal | colorAlbedo
 };
 
 // render(), renderers/ppm_image.zig:30-87: traces pixels [istart, istop) and writes

@@ -15,12 +15,12 @@ using namespace pt;
 
 static void usage() {
     fprintf(stderr, "usage: pt_render [--scene 18|19|20|21] [--width W] [--spp N] [--depth D] [--seed S]\n"
-                    "                 [--device G] [--deterministic] [--chunk C] [--out FILE]\n");
+                    "                 [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--out FILE]\n");
 }
 
 int main(int argc, char **argv) {
     int num_scene = 18, device = 0;               // prompt defaults: main.zig:50,58,63,66
-    unsigned width = 256, spp = 8, depth = 6, chunk = 0;
+    unsigned width = 256, spp = 8, depth = 6, chunk = 0, illumination = PT_ILLUM_RADIANCE;
     unsigned long long seed = 42;
     bool deterministic = false;
     std::string out;
@@ -35,6 +35,13 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--chunk")) chunk = (unsigned)strtoul(need("--chunk"), nullptr, 10);
         else if (!strcmp(argv[i], "--out")) out = need("--out");
         else if (!strcmp(argv[i], "--deterministic")) deterministic = true;
+        else if (!strcmp(argv[i], "--aov")) { // the reference's commented-out colour functions (renderers/ppm_image.zig:64-65)
+            const char *a = need("--aov");
+            if (!strcmp(a, "normal")) illumination = PT_ILLUM_NORMAL;
+            else if (!strcmp(a, "albedo")) illumination = PT_ILLUM_ALBEDO;
+            else if (!strcmp(a, "radiance")) illumination = PT_ILLUM_RADIANCE;
+            else { usage(); return 2; }
+        }
         else { usage(); return 2; }
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -54,6 +61,7 @@ int main(int argc, char **argv) {
     ppm_renderer::Config rcfg{gpu, &camera, &img, 0, img.num_pixels, seed, &cfg, slice.data(), slice.size(), &scene};
     rcfg.deterministic = deterministic;
     rcfg.chunk = chunk;
+    rcfg.illumination = illumination;
     rc = ppm_renderer::render(rcfg);                                      // main.zig:167-177
     if (rc != PT_OK) { fprintf(stderr, "error: render: %s\n", ptgpu_strerror(rc)); ptgpu_destroy(gpu); return 1; }
     pt_stats st;

@@ -47,3 +47,20 @@ def test_pt_render_cli_default_file_name_and_bad_scene(tmp_path):
     from path_tracer_amd import host
     name = host.filepath(19, host.RayTracerConfig(rays_per_subsample=1), host.Image(32), 5)   # utils.zig:113-115
     assert (tmp_path / name).exists(), (name, r.stderr)
+
+
+@pytest.mark.parametrize("aov,illumination", [("normal", 1), ("albedo", 2)])
+def test_pt_render_cli_aov(orc, tmp_path, aov, illumination):
+    """--aov: the reference's commented-out colour functions (renderers/ppm_image.zig:64-65) through the C++ host."""
+    out = tmp_path / "aov.ppm"
+    r = subprocess.run([EXE, "--scene", "21", "--width", "64", "--spp", "2", "--seed", "456", "--aov", aov, "--out", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    spheres, _ = orc.setup_scene(21, 456)
+    cam = orc.camera_preset(21)
+    img = orc.image_new(64)
+    cfg = orc.make_config(img, subpixels=4, rays_per_subsample=2, rebounds=6, seed=456, illumination=illumination)
+    rc, ref_sum, _ = orc.render_sum(spheres, cam, cfg, nthreads=4)
+    rc2, ppm = orc.resolve_ppm(cfg, img, ref_sum)
+    assert rc == 0 and rc2 == 0
+    assert out.read_bytes()[img.header_size:] == bytes(ppm[img.header_size:])

@@ -63,7 +63,7 @@ pub const PtConfig = extern struct {
     tile_pixels: u32,
     tile_count: u32,
     tile_index: u32,
-    reserved: u32,
+    illumination: u32, // 0 radiance, 1 colorNormal, 2 colorAlbedo (illumination.zig)
 };
 
 pub const PtCtx = opaque {};
@@ -176,7 +176,7 @@ pub fn render(cfg: RendererConfig, seed: u64) !void {
         .tile_pixels = 0,
         .tile_count = 1,
         .tile_index = 0,
-        .reserved = 0,
+        .illumination = 0,
     };
     try check(ptgpu_render_ppm(gpu.?, &pc, cfg.slice.ptr, cfg.slice.len, @intCast(u32, img.header_size), @intCast(u32, img.px_size)));
 }
