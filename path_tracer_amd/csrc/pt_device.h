@@ -175,6 +175,13 @@ __device__ __forceinline__ void sphere_hit_point(V3 o, V3 d, float t, float cx, 
     p = vadd(o, vmul(d, t));
     n = vunit(vmul(vsub(p, v3(cx, cy, cz)), 1.0f / radius));
 }
+// The same with 1/radius supplied (the scene tables hold the correctly rounded quotient, computed
+// once per sphere on the host: the same f32 value the division above yields).
+__device__ __forceinline__ void sphere_hit_point_inv(V3 o, V3 d, float t, float cx, float cy, float cz, float inv_radius,
+                                                     V3 &p, V3 &n) {
+    p = vadd(o, vmul(d, t));
+    n = vunit(vmul(vsub(p, v3(cx, cy, cz)), inv_radius));
+}
 
 // material.zig:59-65
 __device__ __forceinline__ V3 reflect(V3 d, V3 n) { return vsub(d, vmul(n, 2.0f * vdot(d, n))); }
@@ -192,31 +199,44 @@ __device__ __forceinline__ bool refract(V3 d, V3 n, float n1_over_n2, V3 &out) {
 }
 
 // material.zig:120-124; Zig's pow(x,5) = x * ((x*x)*(x*x)) (square-and-multiply on mantissas)
-__device__ __forceinline__ float schlick(float cosine, float refraction_index) {
-    float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
-    r0 = r0 * r0;
+__host__ __device__ __forceinline__ float schlick_r0(float refraction_index) { // material.zig:121-122
+    const float r0 = (1.0f - refraction_index) / (1.0f + refraction_index);
+    return r0 * r0;
+}
+__device__ __forceinline__ float schlick_from_r0(float cosine, float r0) {       // material.zig:123
     const float x = 1.0f - cosine;
     const float x2 = x * x;
     const float x4 = x2 * x2;
     return r0 + (1.0f - r0) * (x * x4);
 }
+__device__ __forceinline__ float schlick(float cosine, float refraction_index) {
+    return schlick_from_r0(cosine, schlick_r0(refraction_index));
+}
 
 // Material.scatter, material.zig:191-198 with 43-51 (Lambertian), 79-88 (Metal),
 // 129-167 (Dielectric).  The attenuation is looked up from the material table when
 // the path is finished (it is the albedo, or (1,1,1) for a dielectric).
+//
+// Per-sphere and per-ray values the reference recomputes at every hit are passed in: inv_param =
+// 1/refraction_index and r0 = schlick_r0(refraction_index) (dielectrics only; the scene tables
+// hold them), d_len = |d| (the caller already has |d|^2).  Each is the f32 value the reference's
+// own expression yields, so the result is unchanged.
 template <class R>
-__device__ __forceinline__ V3 scatter(uint32_t kind, float param, V3 d, V3 p, V3 n, R &r) {
+__device__ __forceinline__ V3 scatter_pre(uint32_t kind, float param, float inv_param, float r0, float d_len, V3 d, V3 p, V3 n,
+                                          R &r) {
     V3 out;
     if (kind != 2u) {
         const V3 rnd = random_vector_in_unit_sphere(r);
+        V3 pre; // the vector both kinds normalise
         if (kind == 0u) {
             const V3 target = vadd(p, vadd(n, rnd));
-            out = vunit(vsub(target, p));
+            pre = vsub(target, p);
         } else {
             const V3 sc = reflect(d, n);
             const V3 fc = vmul(rnd, param);
-            out = vunit(vadd(sc, fc));
+            pre = vadd(sc, fc);
         }
+        out = vunit(pre);
     } else {
         V3 outward_normal;
         float n1_over_n2, cosine;
@@ -224,15 +244,15 @@ __device__ __forceinline__ V3 scatter(uint32_t kind, float param, V3 d, V3 p, V3
         if (dn > 0.0f) {
             outward_normal = vunit(v3(-n.x, -n.y, -n.z));
             n1_over_n2 = param;
-            cosine = param * dn / vlen(d);
+            cosine = param * dn / d_len;
         } else {
             outward_normal = n;
-            n1_over_n2 = 1.0f / param;
-            cosine = -dn / vlen(d);
+            n1_over_n2 = inv_param;
+            cosine = -dn / d_len;
         }
         V3 refracted;
         if (refract(d, outward_normal, n1_over_n2, refracted)) {
-            const float reflection_prob = schlick(cosine, param);
+            const float reflection_prob = schlick_from_r0(cosine, r0);
             if (r.next() < reflection_prob) out = reflect(d, n);
             else out = refracted;
         } else {
@@ -242,12 +262,18 @@ __device__ __forceinline__ V3 scatter(uint32_t kind, float param, V3 d, V3 p, V3
     return out;
 }
 
-// illumination.zig:27-34; returns false for DirectionIsNotUnitVector
-__device__ __forceinline__ bool lerp_sky(V3 u, V3 p0, V3 p1, V3 &out) {
-    if (fabsf(vlen(u) - 1.0f) > 0.00001f) return false; // constants.zig:3
+template <class R>
+__device__ __forceinline__ V3 scatter(uint32_t kind, float param, V3 d, V3 p, V3 n, R &r) {
+    return scatter_pre(kind, param, 1.0f / param, schlick_r0(param), vlen(d), d, p, n, r);
+}
+
+// illumination.zig:27-34; returns false for DirectionIsNotUnitVector.  len_u = |u|.
+__device__ __forceinline__ bool lerp_sky_len(V3 u, float len_u, V3 p0, V3 p1, V3 &out) {
+    if (fabsf(len_u - 1.0f) > 0.00001f) return false; // constants.zig:3
     const float t = (u.y + 1.0f) * 0.5f;
     out = vadd(vmul(p0, 1.0f - t), vmul(p1, t));
     return true;
 }
+__device__ __forceinline__ bool lerp_sky(V3 u, V3 p0, V3 p1, V3 &out) { return lerp_sky_len(u, vlen(u), p0, p1, out); }
 
 } // namespace ptdev

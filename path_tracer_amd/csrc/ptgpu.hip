@@ -82,7 +82,8 @@ struct KParams {
     uint32_t total_threads;
     const float4 *filt; // (cx, cy, cz, threshold) padded to a multiple of kPad
     const float4 *geom; // (cx, cy, cz, radius)
-    const float4 *mat;  // (albedo r, g, b, param)
+    const float4 *mat;  // (albedo r, g, b, param); dielectrics: (1/ri, schlick r0, 0, ri)
+    const float *inv_radius; // 1/radius, correctly rounded (the value sphere.zig:88 computes per hit)
     const uint32_t *kind;
     float *part;        // direct ? frame[W*H][3] : [nchunks][npix][3] partial sums
     uint32_t *stack;    // [rebounds][total_threads] hit ids
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
     __shared__ float s_radius[MULTI_TILE ? 1 : kTile];
-    __shared__ float4 s_mat[MULTI_TILE ? 1 : kTile];   // (albedo r, g, b, param); kind in s_kind
+    __shared__ float s_inv_radius[MULTI_TILE ? 1 : kTile];
+    __shared__ float4 s_mat[MULTI_TILE ? 1 : kTile];   // (albedo r, g, b, param) | (1/ri, r0, 0, ri); kind in s_kind
     __shared__ uint8_t s_kind[MULTI_TILE ? 4 : kTile];
 
     const uint32_t tid = threadIdx.x;
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
         for (uint32_t i = tid; i < P.nspheres; i += kBlock) {
             s_radius[i] = P.geom[i].w;
+            s_inv_radius[i] = P.inv_radius[i];
             s_mat[i] = P.mat[i];
             s_kind[i] = (uint8_t)P.kind[i];
         }
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float4 f = s_filt[j];
         return make_float4(f.x, f.y, f.z, s_radius[j]);
     };
+    auto inv_radius_of = [&](uint32_t j) -> float { return MULTI_TILE ? P.inv_radius[j] : s_inv_radius[j]; };
     auto mat_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.mat[j] : s_mat[j]; };
     auto kind_of = [&](uint32_t j) -> uint32_t { return MULTI_TILE ? P.kind[j] : (uint32_t)s_kind[j]; };
 
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
 
         // ---- phase C: radiance step (illumination.zig:76-90) ---------------------
         if (alive) {
+            const float d_len = sqrtf(a); // |d|: lerp's unit check (illumination.zig:28) and Dielectric's cosine (material.zig:140,144)
             bool done = false;
             V3 color = v3(0.f, 0.f, 0.f);
             bool ok = true;
@@ -396,8 +401,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     const float4 m = mat_of((uint32_t)hit);
                     const uint32_t kind = kind_of((uint32_t)hit);
                     V3 p, n;
-                    sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, n);
-                    const V3 nd = scatter(kind, m.w, d, p, n, rng);
+                    sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
+                    const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
 #ifndef PT_EXPERIMENT_NO_STACK // tools/build_variant.sh timing experiment (breaks parity)
                     P.stack[(size_t)bounce * P.total_threads + gtid] = (uint32_t)hit;
 #endif
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     o = p; d = nd;
                 }
             } else {
-                ok = lerp_sky(d, P.blend_start, P.blend_stop, color); // illumination.zig:88
+                ok = lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color); // illumination.zig:88
                 // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
                 for (uint32_t b = bounce; b > 0; --b) {
 #ifndef PT_EXPERIMENT_NO_STACK
@@ -647,6 +652,7 @@ struct ptgpu_ctx {
     uint32_t nspheres = 0, n_pad = 0;
     float4 *d_filt = nullptr, *d_geom = nullptr, *d_mat = nullptr;
     uint32_t *d_kind = nullptr;
+    float *d_inv_radius = nullptr;
     bool have_camera = false;
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
@@ -724,7 +730,7 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
 extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PT_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
+    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -773,26 +779,33 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n_pad = (n + kPad - 1) / kPad * kPad;
     std::vector<float4> filt(n_pad), geom(n), mat(n);
+    std::vector<float> inv_radius(n);
     std::vector<uint32_t> kind(n);
     for (uint32_t i = 0; i < n; ++i) {
         const pt_sphere &s = spheres[i];
         filt[i] = make_float4(s.cx, s.cy, s.cz, filter_threshold(s));
         geom[i] = make_float4(s.cx, s.cy, s.cz, s.radius);
-        mat[i] = make_float4(s.ar, s.ag, s.ab, s.param);
+        // per-sphere values the reference recomputes at every hit, in the same f32 arithmetic (this file is
+        // built with -ffp-contract=off; host float division is correctly rounded like the device's)
+        inv_radius[i] = 1.0f / s.radius;                                   // sphere.zig:88
+        mat[i] = (s.kind == PT_DIELECTRIC) ? make_float4(1.0f / s.param, schlick_r0(s.param), 0.0f, s.param) // material.zig:143,121
+                                           : make_float4(s.ar, s.ag, s.ab, s.param);
         kind[i] = s.kind;
     }
     for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, 0.f, INFINITY); // never a candidate
-    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind};
+    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius};
     for (void *p : olds) if (p) HIP_TRY(ctx, hipFree(p));
-    ctx->d_filt = ctx->d_geom = ctx->d_mat = nullptr; ctx->d_kind = nullptr;
+    ctx->d_filt = ctx->d_geom = ctx->d_mat = nullptr; ctx->d_kind = nullptr; ctx->d_inv_radius = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_filt, n_pad * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_geom, n * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_mat, n * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_kind, n * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_inv_radius, n * sizeof(float)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_filt, filt.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_kind, kind.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_inv_radius, inv_radius.data(), n * sizeof(float), hipMemcpyHostToDevice));
     ctx->nspheres = n;
     ctx->n_pad = n_pad;
     return PT_OK;
@@ -900,7 +913,7 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
-    P.filt = ctx->d_filt; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind;
+    P.filt = ctx->d_filt; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = part; P.stack = ctx->d_stack; P.counters = ctx->d_counters;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
