@@ -172,3 +172,18 @@ def test_convergence_psnr_4096spp(orc, gpu):
     mse = float(np.mean((g.astype(np.float64) - r.astype(np.float64)) ** 2))
     psnr = 10.0 * np.log10(1.0 / mse)
     assert psnr >= 40.0, psnr
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_config2_full_hd_frame_against_oracle(orc, gpu, deterministic):
+    """configs[2]'s frame (scene 21, 1920x1080, depth 50) at 4 paths per pixel: every one of the 2 073 600
+    pixels equals the oracle's, bit for bit (8.3 M paths, ~17 M rays)."""
+    host, scene, cam = _setup(gpu, 21, 456)
+    img = host.Image(1920)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=1, rebounds=50)
+    cfg = host.make_pt_config(img, rt, seed=456, chunk=2, deterministic=deterministic)
+    got = gpu.render_sum(cfg)
+    ref, st = _oracle_sum(orc, scene.spheres, cam.pod, cfg, nthreads=32)
+    gst = gpu.stats()
+    assert gst.paths == st.paths == 1920 * 1080 * 4 and gst.rays == st.rays
+    np.testing.assert_array_equal(got, ref)
