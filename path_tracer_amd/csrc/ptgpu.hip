@@ -172,23 +172,30 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
             float4 fr[kSub];
 #pragma unroll
             for (int k = 0; k < kSub; ++k) fr[k] = s_filt[k];
-            for (uint32_t j0 = 0; j0 < tn; j0 += kPad) {
+            auto test_and_refill = [&](float4 &f, uint32_t next) {
+                float q = f.x * hx;
+                q = fmaf(f.y, hy, q);
+                q = fmaf(f.z, hz, q);
+                float s = fmaf(f.x, wx, E);
+                s = fmaf(f.y, wy, s);
+                s = fmaf(f.z, wz, s);
+                const float F = fmaf(q, q, s);
+                // candidate iff F >= T
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.w), "v"(F) : "vcc");
+                f = s_filt[next];
+            };
+            uint32_t j0 = 0;
+            for (; j0 + 32u <= tn; j0 += 32u) { // one whole mask word per iteration: 32 tests, LDS offsets are immediates
 #pragma unroll
-                for (int k = 0; k < kPad; ++k) {
-                    float4 &f = fr[k % kSub];
-                    float q = f.x * hx;
-                    q = fmaf(f.y, hy, q);
-                    q = fmaf(f.z, hz, q);
-                    float s = fmaf(f.x, wx, E);
-                    s = fmaf(f.y, wy, s);
-                    s = fmaf(f.z, wz, s);
-                    const float F = fmaf(q, q, s);
-                    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.w), "v"(F) : "vcc");
-                    f = s_filt[j0 + (uint32_t)k + (uint32_t)kSub];
+                for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)k + (uint32_t)kSub);
+                store_word(j0 >> 5, 32u);
+            }
+            if (j0 < tn) {                      // the last, partial word (a multiple of kPad tests)
+                for (; j0 < tn; j0 += kPad) {
+#pragma unroll
+                    for (int k = 0; k < kPad; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)k + (uint32_t)kSub);
                 }
-                const uint32_t done = j0 + kPad;
-                if ((done & 31u) == 0u) store_word((done >> 5) - 1u, 32u);
-                else if (done == tn) store_word(nw - 1u, g_last);
+                store_word(nw - 1u, g_last);
             }
             // ---- exact Sphere.is_hit (sphere.zig:63-103) on the survivors, ascending sphere
             // index, strict '<' (scene.zig:102): each lane walks its own words/bits; the
