@@ -58,6 +58,9 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 #ifndef PT_SUB
 #define PT_SUB 4
 #endif
+#ifndef PT_WORDS_PER_ITER
+#define PT_WORDS_PER_ITER 4 // mask words (x32 tests) per unrolled scan-loop iteration; measured 1/2/4/8: 432.3/429.8/428.6/433.0 ms
+#endif
 
 constexpr int kSub = PT_SUB;         // filter records held in registers ahead of their tests (software pipeline depth)
 static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
@@ -185,7 +188,15 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
                 f = s_filt[next];
             };
             uint32_t j0 = 0;
-            for (; j0 + 32u <= tn; j0 += 32u) { // one whole mask word per iteration: 32 tests, LDS offsets are immediates
+            for (; j0 + 32u * PT_WORDS_PER_ITER <= tn; j0 += 32u * PT_WORDS_PER_ITER) { // whole mask words per iteration: LDS offsets are immediates
+#pragma unroll
+                for (int w = 0; w < PT_WORDS_PER_ITER; ++w) {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)(32 * w + k) + (uint32_t)kSub);
+                    store_word((j0 >> 5) + (uint32_t)w, 32u);
+                }
+            }
+            for (; j0 + 32u <= tn; j0 += 32u) {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)k + (uint32_t)kSub);
                 store_word(j0 >> 5, 32u);
