@@ -68,7 +68,11 @@ struct PhiloxRng { // stochastic mode
     __device__ __forceinline__ float next() {
         const uint32_t k = n & 3u;
         if (k == 0) philox4x32_10(pixel, sample, n >> 2, 0u, k0, k1, b0, b1, b2, b3);
-        const uint32_t w = (k == 0) ? b0 : (k == 1) ? b1 : (k == 2) ? b2 : b3;
+        // Select among VALUES read unconditionally: with the member reads inside the arms of ?: the optimizer
+        // sinks them into one load from a selected ADDRESS, and the whole struct then lives in scratch memory
+        // (seen in the ISA as scratch_store/scratch_load around every Philox call).
+        const uint32_t x0 = b0, x1 = b1, x2 = b2, x3 = b3;
+        const uint32_t w = (k == 0) ? x0 : (k == 1) ? x1 : (k == 2) ? x2 : x3;
         n++;
         return u32_to_float(w);
     }
@@ -80,8 +84,9 @@ struct PhiloxRng { // stochastic mode
         uint32_t k = n & 3u;
         if (k == 3u) { n += 1u; k = 0u; }
         if (k == 0u) philox4x32_10(pixel, sample, n >> 2, 0u, k0, k1, b0, b1, b2, b3);
-        const uint32_t w0 = (k == 0u) ? b0 : (k == 1u) ? b1 : b2;
-        const uint32_t w1 = (k == 0u) ? b1 : (k == 1u) ? b2 : b3;
+        const uint32_t x0 = b0, x1 = b1, x2 = b2, x3 = b3; // values, not addresses: see next()
+        const uint32_t w0 = (k == 0u) ? x0 : (k == 1u) ? x1 : x2;
+        const uint32_t w1 = (k == 0u) ? x1 : (k == 1u) ? x2 : x3;
         n += 2u;
         x = u32_to_float(w0); y = u32_to_float(w1);
     }
@@ -89,9 +94,10 @@ struct PhiloxRng { // stochastic mode
         uint32_t k = n & 3u;
         if (k > 1u) { n = (n + 3u) & ~3u; k = 0u; }
         if (k == 0u) philox4x32_10(pixel, sample, n >> 2, 0u, k0, k1, b0, b1, b2, b3);
-        const uint32_t w0 = (k == 0u) ? b0 : b1;
-        const uint32_t w1 = (k == 0u) ? b1 : b2;
-        const uint32_t w2 = (k == 0u) ? b2 : b3;
+        const uint32_t x0 = b0, x1 = b1, x2 = b2, x3 = b3; // values, not addresses: see next()
+        const uint32_t w0 = (k == 0u) ? x0 : x1;
+        const uint32_t w1 = (k == 0u) ? x1 : x2;
+        const uint32_t w2 = (k == 0u) ? x2 : x3;
         n += 3u;
         x = u32_to_float(w0); y = u32_to_float(w1); z = u32_to_float(w2);
     }
