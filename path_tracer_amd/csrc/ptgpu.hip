@@ -5,8 +5,8 @@
 // Kernel design (DESIGN.md has the long form):
 //   * one lane = one path; a persistent wave keeps all 64 lanes busy by refilling a
 //     lane's path as soon as it terminates (next sample of its work item, or a new
-//     work item from an atomic queue, fetched with one atomic per wave via
-//     ballot/popcount) — replaces the thread split of multithreading.zig;
+//     work item from an atomic queue; a wave reserves 64 items per atomic and deals them
+//     out by ballot/popcount ranks) — replaces the thread split of multithreading.zig;
 //   * Scene.is_hit (scene.zig:96-110) = a linear scan over a filter table
 //     (cx,cy,cz,threshold) staged into LDS in tiles: 7 FMAs + 1 compare per sphere
 //     decide conservatively whether the reference's discriminant can be >= 0 and one
