@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # before libptgpu: one HIP runtime per process (torch bundles its own)
 torch.cuda.init()
 import numpy as np
-from oracle import oracle as o
+from path_tracer_amd import host
 from path_tracer_amd.gpu import GpuContext
 
 def main():
@@ -14,11 +14,11 @@ def main():
     chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     scene = int(sys.argv[5]) if len(sys.argv) > 5 else 21
     if scene > 100:
-        sp = o.scene_synthetic(scene, 1); cam = o.camera_preset(21)
+        sp = host.Scene().sceneSynthetic(scene, 1).spheres; cam = host.Camera.preset(21).pod
     else:
-        sp, _ = o.setup_scene(scene, 456); cam = o.camera_preset(scene)
-    img = o.image_new(width)
-    cfg = o.make_config(img, subpixels=4, rays_per_subsample=spp, rebounds=depth, seed=456, chunk=chunk)
+        sp = host.Scene().setupScene(456, scene).spheres; cam = host.Camera.preset(scene).pod
+    img = host.Image(width)
+    cfg = host.make_pt_config(img, host.RayTracerConfig(subpixels=4, rays_per_subsample=spp, rebounds=depth), seed=456, chunk=chunk)
     g = GpuContext(0)
     info = g.device_info()
     g.set_scene(sp); g.set_camera(cam)
