@@ -169,7 +169,10 @@ def main():
         if args.rehearse_gloo:
             out["rehearsal"] = "all ranks on ONE GPU over gloo: plumbing check only, not a benchmark result"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.width, args.depth, args.seed)
+            except Exception as e:  # the GPU line must not be lost to a host-side problem (e.g. no compiler for the oracle)
+                out["cpu_baseline"] = {"value": None, "unit": "paths/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
