@@ -170,6 +170,10 @@ __device__ __forceinline__ bool sphere_near_root(V3 o, V3 d, float a, float cx, 
     const float c = vlen2(oc) - radius * radius;
     const float discriminant = half_b * half_b - a * c;
     if (discriminant < 0.0f) return false;
+    // Shortcut with the reference's outcome: half_b >= 0 makes t = (-half_b - sqrtd) / a <= 0, which fails
+    // t > t_min for any t_min >= 0 (NaN operands fail it too) — the sphere is behind the origin, or the ray
+    // is leaving its surface.  About half of the filter's survivors end here, before the sqrt and the divide.
+    if (t_min >= 0.0f && half_b >= 0.0f) return false;
     const float sqrtd = sqrtf(discriminant);
     const float t = (-half_b - sqrtd) / a;
     if (t < t_max && t > t_min) { t_out = t; return true; }
