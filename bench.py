@@ -71,6 +71,12 @@ def main():
     ap.add_argument("--seed", type=int, default=456)
     ap.add_argument("--chunk", type=int, default=16, help="samples per GPU work item")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spheres", type=int, default=0,
+                    help="0 (default) = scene 21, the headline config; N > 0 = the synthetic random-sphere scene of N spheres "
+                         "(BASELINE configs[4] uses 100000 with --spp 64 --split tiles)")
+    ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
+                    help="multi-GPU partition: sample ranges (weak scaling: every rank traces 4 x spp paths per pixel) or "
+                         "interleaved 256-pixel tiles of ONE frame of 4 x spp paths per pixel (strong scaling)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: run the N>1 plumbing on ONE GPU (all ranks on cuda:0, gloo all_reduce "
                          "instead of the RCCL reduce); the JSON line is marked and is not a benchmark result")
@@ -95,9 +101,10 @@ def main():
     from path_tracer_amd.gpu import GpuContext
 
     img = host.Image(args.width)
-    # weak scaling: N ranks trace N x (4 x spp) paths per pixel in total
-    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=args.spp * world, rebounds=args.depth)
-    scene = host.Scene().setupScene(args.seed, 21)
+    # sample split = weak scaling: N ranks trace N x (4 x spp) paths per pixel in total; tile split = one frame
+    weak = args.split == "samples"
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=args.spp * (world if weak else 1), rebounds=args.depth)
+    scene = host.Scene().sceneSynthetic(args.spheres, 1) if args.spheres > 0 else host.Scene().setupScene(args.seed, 21)
     camera = host.Camera.preset(21, img.aspect_ratio)
     gpu = GpuContext(local_rank)
     gpu.set_scene(scene.spheres)
@@ -106,7 +113,7 @@ def main():
     frame = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device="cuda")
 
     def step():
-        render_sum_distributed(render_into, img, rt, args.seed, split="samples", chunk=args.chunk, frame=frame,
+        render_sum_distributed(render_into, img, rt, args.seed, split=args.split, chunk=args.chunk, frame=frame,
                                everywhere=args.rehearse_gloo)  # gloo has no CUDA reduce, only all_reduce
         return gpu.stats()
 
@@ -141,22 +148,28 @@ def main():
 
     if rank == 0:
         nsph = len(scene.spheres)
+        scene_name = ("synthetic random-sphere scene (%d spheres, generator seed 1)" % nsph if args.spheres > 0
+                      else "scene 21 (488 spheres, seed %d)" % args.seed)
+        headline = args.spheres == 0 and args.width == 1920 and args.spp == 256 and args.depth == 50
         k_ms = sum(kernel_ms) / len(kernel_ms)
         flops_per_launch = algorithmic_flops(paths / args.steps, rays / args.steps, nsph)
         achieved = flops_per_launch / (k_ms * 1e-3)
         out = {
-            "metric": "paths/sec (scene 21, 1920x1080, 1024 spp, depth 50)",
+            "metric": "paths/sec (scene 21, 1920x1080, 1024 spp, depth 50)" if headline else
+                      "paths/sec (%s, %dx%d, %d spp, depth %d)" % (scene_name, img.width, img.height, 4 * args.spp, args.depth),
             "value": all_paths / dt_max,
             "unit": "paths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: scene 21 (488 spheres, seed %d), %dx%d, %d paths/pixel per GPU "
-                                   "(subpixels 4 x %d), depth %d" % (args.seed, img.width, img.height, 4 * args.spp,
-                                                                       args.spp, args.depth),
-                       "parallelism": "sample-range split x%d + RCCL reduce(SUM) of fp32 sums" % world if world > 1 else "1 GPU",
-                       "chunk": args.chunk, "global_paths_per_pixel": 4 * args.spp * world},
+            "config": {"workload": "%s, %dx%d, %d paths/pixel per %s (subpixels 4 x %d), depth %d"
+                                   % (("BASELINE configs[2]: " if headline else "") + scene_name, img.width, img.height,
+                                      4 * args.spp, "GPU" if weak else "frame", args.spp, args.depth),
+                       "parallelism": "1 GPU" if world == 1 else
+                                      ("sample-range split x%d" if weak else "interleaved 256-pixel tile split x%d") % world
+                                      + " + RCCL reduce(SUM) of fp32 sums",
+                       "chunk": args.chunk, "global_paths_per_pixel": 4 * args.spp * (world if weak else 1)},
             "mrays_per_s": all_rays / dt_max * 1e-6,
             "rays_per_path": all_rays / all_paths,
             "roofline": {"bound": "valu", "achieved": achieved * 1e-12, "peak": PEAK_FP32_VALU * 1e-12, "unit": "TFLOP/s",
