@@ -40,7 +40,8 @@ enum {
     PT_ERR_VALUE_EXCEEDS_MAX = -6,  /* utils.zig:63-65 ValueExceedsMaxValue          */
     PT_ERR_SCENE_NOT_AVAILABLE = -7,/* errors.zig:2  UserError.SceneNotAvailable     */
     PT_ERR_NO_SPACE = -8,           /* caller buffer too small (Zig: NoSpaceLeft)    */
-    PT_ERR_UNSUPPORTED = -9         /* e.g. max_px_value != 255                      */
+    PT_ERR_UNSUPPORTED = -9,        /* e.g. max_px_value != 255                      */
+    PT_ERR_RCCL = -11               /* an RCCL call failed (ptgpu_multi_*)           */
 };
 
 /* ---- material kinds: the tags of material.zig:174-178 ------------------- */
@@ -126,8 +127,9 @@ typedef struct pt_stats {
     uint64_t not_unit;     /* lerp() directions failing illumination.zig:29          */
     uint64_t wave_steps;   /* ray steps executed by waves (rays / (64*wave_steps) = lane utilisation) */
     uint64_t flush_iters;  /* wave iterations of the exact-test loop                 */
-    double kernel_ms;      /* HIP-event time of the path-tracing kernel              */
-    double total_ms;       /* kernel + resolve (+ copies for host-pointer variants)  */
+    double kernel_ms;      /* HIP-event time of the path-tracing kernel (of all segments, incl. their chunk sums, when segments > 1) */
+    double total_ms;       /* kernel + chunk sums                                    */
+    uint64_t segments;     /* megakernel launches the render took (PT_LIMIT_PARTIAL_BYTES) */
 } pt_stats;
 
 typedef struct ptgpu_ctx ptgpu_ctx;
@@ -160,10 +162,12 @@ int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum
  * sum*(1/subpixels)*(1/rays_per_subsample), *max_px_value, truncating u8, the
  * 12-byte "%3d %3d %3d\n" record of render_targets/ppm_image.zig:93-103.
  * d_records receives (idx_stop-idx_start)*12 bytes (record of pixel idx at
- * (idx-idx_start)*12); either output may be NULL.  d_rgb8 receives 3 bytes/pixel.
- * A colour above max_px_value (the reference asserts col <= 255 and its
- * @floatToInt(u8) is undefined beyond) is written clamped to 255 and the call
- * returns PT_ERR_VALUE_EXCEEDS_MAX after writing every record. */
+ * (idx-idx_start)*12) and must be 4-byte aligned (records are written as three dwords);
+ * either output may be NULL.  d_rgb8 receives 3 bytes/pixel.
+ * A colour above max_px_value (col > 255: the reference asserts col <= 255,
+ * renderers/ppm_image.zig:76, and its @floatToInt(u8) is undefined from 256 on) is
+ * written clamped to 255 and the call returns PT_ERR_VALUE_EXCEEDS_MAX after writing
+ * every record. */
 int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const float *d_rgb_sum,
                          uint8_t *d_records, uint8_t *d_rgb8, void *stream);
 
@@ -194,10 +198,19 @@ enum {
     PT_FN_REFLECT = 6,     /* material.zig:59   in: d,n (6)                       out: r (3)               */
     PT_FN_LERP = 7,        /* illumination.zig:27 in: d,p0,p1 (9)                 out: err,rgb (4)         */
     PT_FN_PHILOX = 8,      /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
-    PT_FN_SCENE_HIT_FILTERED = 9 /* scene.zig:96 as the megakernel evaluates it (LDS filter + exact pass): in/out as PT_FN_SCENE_HIT */
+    PT_FN_SCENE_HIT_FILTERED = 9, /* scene.zig:96 as the megakernel evaluates it (LDS filter + exact pass): in/out as PT_FN_SCENE_HIT */
+    PT_FN_FILTER_BIT = 10  /* the LDS filter's verdict for one (ray, sphere) pair: in: o,d,c,r (10)  out: candidate bit,
+                              reference discriminant of sphere.zig:74 (2).  Invariant: discriminant >= 0 => bit == 1 */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);
+
+/* Limits.  PT_LIMIT_PARTIAL_BYTES (default 2 GiB): upper bound of the device buffer that holds the
+ * chunk partial sums (chunks x pixels x 12 B).  A render that needs more is traced in segments of
+ * pixels, one kernel launch each, through the same buffer; the result is bit-identical (a pixel's
+ * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took. */
+enum { PT_LIMIT_PARTIAL_BYTES = 0 };
+int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
 
 /* Diagnostics. */
 int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);

@@ -671,19 +671,22 @@ int orc_resolve_ppm(const orc_config *cfg, const orc_image *img, const float *rg
     const float k1 = 1.0f / (float)cfg->subpixels;
     const float k2 = 1.0f / (float)cfg->rays_per_subsample;
     const float max_val_f = (float)img->max_px_value;
+    int exceeded = 0;
     for (uint32_t idx = cfg->idx_start; idx < cfg->idx_stop; idx++) {
         vec3 c = v3(rgb_sum[3 * (size_t)idx], rgb_sum[3 * (size_t)idx + 1], rgb_sum[3 * (size_t)idx + 2]);
         c = vmul(vmul(c, k1), k2);
         const vec3 col = vmul(c, max_val_f);
         const float colf[3] = {col.x, col.y, col.z};
         char ascii[32];
+        /* renderers/ppm_image.zig:75-77 asserts col <= 255: reported after every record is written (clamped) */
+        if (col.x > max_val_f || col.y > max_val_f || col.z > max_val_f) exceeded = 1;
         const int rc = orc_rgb_to_ascii(img, colf, ascii, sizeof ascii);
         if (rc != ORC_OK) return rc;
         const size_t offset = (size_t)idx * img->px_size;
         if (img->header_size + offset + img->px_size > slice_len) return ORC_ERR_NO_SPACE;
         memcpy(slice + img->header_size + offset, ascii, img->px_size);
     }
-    return ORC_OK;
+    return exceeded ? ORC_ERR_VALUE_EXCEEDS_MAX : ORC_OK;
 }
 
 int orc_render_ppm(const orc_sphere *sp, uint32_t n, const orc_camera *cam, const orc_config *cfg, const orc_image *img,

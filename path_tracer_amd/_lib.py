@@ -21,15 +21,19 @@ PT_ERR_VALUE_EXCEEDS_MAX = -6
 PT_ERR_SCENE_NOT_AVAILABLE = -7
 PT_ERR_NO_SPACE = -8
 PT_ERR_UNSUPPORTED = -9
+PT_ERR_RCCL = -11
+
+PT_LIMIT_PARTIAL_BYTES = 0
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
 
 (PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
- PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED) = range(10)
+ PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT) = range(11)
 FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
     PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
-    PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8)}
+    PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8),
+    PT_FN_FILTER_BIT: (10, 2)}
 
 # pt_sphere: 36 bytes
 SPHERE_DTYPE = np.dtype(
@@ -60,13 +64,14 @@ class pt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("segments", C.c_uint64)]
 
 
 assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104
 
 # every symbol include/ptgpu.h declares
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
+           "ptgpu_set_limit",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
            "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
            "ptgpu_abi_version"]
@@ -98,6 +103,7 @@ def load():
     L.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32]
     L.ptgpu_set_camera.argtypes = [vp, C.POINTER(pt_camera)]
     L.ptgpu_render_sum_device.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.ptgpu_set_limit.argtypes = [vp, C.c_int, C.c_uint64]
     L.ptgpu_render_sum_host.argtypes = [vp, C.POINTER(pt_config), vp]
     L.ptgpu_render_mean_host.argtypes = [vp, C.POINTER(pt_config), vp]
     L.ptgpu_resolve_device.argtypes = [vp, C.POINTER(pt_config), vp, vp, vp, vp]

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -65,6 +66,7 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 constexpr int kSub = PT_SUB;         // filter records held in registers ahead of their tests (software pipeline depth)
 static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
+#define kNaN __builtin_nanf("")
 
 enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 16 };
 
@@ -77,7 +79,8 @@ struct KParams {
     uint32_t illum;                 // PT_ILLUM_*
     uint32_t seed_lo, seed_hi;
     uint32_t idx_start, idx_stop;   // pixel range
-    uint32_t npix;                  // pixel slots this launch owns (all of the range, or this owner's tiles)
+    uint32_t slot0;                 // first pixel slot of this launch (segment of the range / of this owner's tiles)
+    uint32_t npix;                  // pixel slots this launch covers: [slot0, slot0 + npix)
     uint32_t tile_pixels, tile_count, tile_index; // interleaved tile ownership (0 = off)
     uint32_t direct;                // 1: one chunk, sums go straight to the frame at pixel*3
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
@@ -127,6 +130,31 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #else
 #define PT_FLUSH_ACC(a, b)
 #endif
+// Per-ray constants of the conservative filter: with dh = d/|d|,
+//   F(c) = (c.dh)^2 + c.w + E = (oc.dh)^2 - |oc|^2 + |c|^2 + Keps*|o|^2,   candidate iff F >= T(sphere).
+struct FilterRay { float hx, hy, hz, wx, wy, wz, E; };
+__device__ __forceinline__ FilterRay filter_ray_setup(V3 o, V3 d, float a) {
+    FilterRay r;
+    const float inv = rsqrtf(a);
+    r.hx = d.x * inv; r.hy = d.y * inv; r.hz = d.z * inv;
+    const float od = fmaf(o.z, r.hz, fmaf(o.y, r.hy, o.x * r.hx));
+    const float oo = fmaf(o.z, o.z, fmaf(o.y, o.y, o.x * o.x));
+    r.wx = 2.0f * fmaf(-od, r.hx, o.x);
+    r.wy = 2.0f * fmaf(-od, r.hy, o.y);
+    r.wz = 2.0f * fmaf(-od, r.hz, o.z);
+    r.E = fmaf(od, od, (kKeps - 1.0f) * oo);
+    return r;
+}
+__device__ __forceinline__ float filter_value(const FilterRay &r, float cx, float cy, float cz) {
+    float q = cx * r.hx;
+    q = fmaf(cy, r.hy, q);
+    q = fmaf(cz, r.hz, q);
+    float s = fmaf(cx, r.wx, r.E);
+    s = fmaf(cy, r.wy, s);
+    s = fmaf(cz, r.wz, s);
+    return fmaf(q, q, s);
+}
+
 template <bool MULTI_TILE, class GeomOf>
 __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
                                                       uint32_t tid, GeomOf geom_of, V3 o, V3 d, float a, float t_min, float t_max,
@@ -135,14 +163,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
     constexpr uint32_t TILE = (uint32_t)kTile;
     (void)t_flush;
     {
-        const float inv = rsqrtf(a);
-        const float hx = d.x * inv, hy = d.y * inv, hz = d.z * inv;
-        const float od = fmaf(o.z, hz, fmaf(o.y, hy, o.x * hx));
-        const float oo = fmaf(o.z, o.z, fmaf(o.y, o.y, o.x * o.x));
-        const float wx = 2.0f * fmaf(-od, hx, o.x);
-        const float wy = 2.0f * fmaf(-od, hy, o.y);
-        const float wz = 2.0f * fmaf(-od, hz, o.z);
-        const float E = fmaf(od, od, (kKeps - 1.0f) * oo);
+        const FilterRay fray = filter_ray_setup(o, d, a);
         // One bit per tested sphere, 32 tests per word: after the compare, VCC is shifted
         // into the lane's word with a single v_addc (m = m + m + vcc) — no branch, no
         // scalar work per test.  A word's first test ends up in its highest used bit.
@@ -176,13 +197,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
 #pragma unroll
             for (int k = 0; k < kSub; ++k) fr[k] = s_filt[k];
             auto test_and_refill = [&](float4 &f, uint32_t next) {
-                float q = f.x * hx;
-                q = fmaf(f.y, hy, q);
-                q = fmaf(f.z, hz, q);
-                float s = fmaf(f.x, wx, E);
-                s = fmaf(f.y, wy, s);
-                s = fmaf(f.z, wz, s);
-                const float F = fmaf(q, q, s);
+                const float F = filter_value(fray, f.x, f.y, f.z);
                 // candidate iff F >= T
                 asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.w), "v"(F) : "vcc");
                 f = s_filt[next];
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     uint32_t pixel = 0, sample = 0, s_end = 0, out_slot = 0;
     bool has_item = false;
     V3 accum = v3(0.f, 0.f, 0.f);
-    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 1.f, 0.f);
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(kNaN, kNaN, kNaN); // parked (see phase A) until the first path starts
     uint32_t bounce = 0;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
@@ -343,20 +358,22 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                 else pool_next += cnt;
                 if (want) {
                     const uint32_t item = item_;
+                    // A lane without a path parks on a NaN direction: no filter compare passes, so it
+                    // adds no candidates and no exact-pass iterations to its wave.
+                    o = v3(0.f, 0.f, 0.f); d = v3(kNaN, kNaN, kNaN);
                     if (item < total_items) {
                         const uint32_t k = item / P.npix;
                         const uint32_t po = item - k * P.npix;
-                        pixel = slot_to_pixel(po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
+                        pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
                         sample = P.s0 + k * P.chunk;
                         s_end = min(sample + P.chunk, P.s1);
                         out_slot = P.direct ? pixel : item; // frame[pixel] or part[k][po]
                         accum = v3(0.f, 0.f, 0.f);
-                        has_item = pixel < P.idx_stop;      // the owner's last tile may be cut by the range
-                        if (!has_item) s_end = sample;
+                        has_item = pixel < P.idx_stop;      // the owner's last tile may be cut by the range:
+                        if (!has_item) s_end = sample;      // an empty item — the lane idles this step and asks again
                         n_paths += s_end - sample;
                     } else {
                         alive = false;
-                        o = v3(0.f, 0.f, 0.f); d = v3(0.f, 1.f, 0.f);
                     }
                 }
             }
@@ -366,7 +383,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         } else {
             if (__ballot(alive) == 0ull) break;
         }
-        if (alive && need_path) {
+        // sample == s_end here only for a lane whose new item was empty (cut tile): it must not start a path
+        if (alive && need_path && sample != s_end) {
             // renderers/ppm_image.zig:50-51,61-63
             rng.start_path(pixel, sample);
             const uint32_t i_col = pixel % P.width;
@@ -389,13 +407,14 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         int hit = -1;
         scene_is_hit_filtered<MULTI_TILE>(P.filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                           n_cands, n_flush_iters, t_flush);
-        if (alive) n_rays++;
+        const bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
+        if (tracing) n_rays++;
         n_wave_steps++;
         PT_STAMP(tC0);
         PT_ACC(1, tB0, tC0);
 
         // ---- phase C: radiance step (illumination.zig:76-90) ---------------------
-        if (alive) {
+        if (tracing) {
             const float d_len = sqrtf(a); // |d|: lerp's unit check (illumination.zig:28) and Dielectric's cosine (material.zig:140,144)
             bool done = false;
             V3 color = v3(0.f, 0.f, 0.f);
@@ -478,12 +497,12 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
 }
 
 // Sum the chunk partials of a pixel in chunk order: total = p0; total += p1; ...
-__global__ void pt_sum_chunks(const float *part, uint32_t npix, uint32_t nchunks, uint32_t idx_start, uint32_t idx_stop,
+__global__ void pt_sum_chunks(const float *part, uint32_t slot0, uint32_t npix, uint32_t nchunks, uint32_t idx_start, uint32_t idx_stop,
                               uint32_t tile_pixels, uint32_t tile_count, uint32_t tile_index, float *rgb_sum) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // over npix*3
     if (i >= npix * 3u) return;
     const uint32_t po = i / 3u, c = i - po * 3u;
-    const uint32_t pixel = slot_to_pixel(po, idx_start, tile_pixels, tile_count, tile_index);
+    const uint32_t pixel = slot_to_pixel(slot0 + po, idx_start, tile_pixels, tile_count, tile_index);
     if (pixel >= idx_stop) return;
     float total = part[i];
     for (uint32_t k = 1; k < nchunks; ++k) total = total + part[(size_t)k * npix * 3u + i];
@@ -521,9 +540,8 @@ __global__ void pt_resolve(const float *rgb_sum, uint32_t idx_start, uint32_t np
         // reference's ReleaseFast build — clamped here and counted.
         uint32_t v;
         if (!(col > 0.0f)) v = 0u;
-        else if (col >= 256.0f) { v = 255u; atomicAdd(&counters[CNT_N - 1], 1ull); }
+        else if (col > max_val_f) { v = 255u; atomicAdd(&counters[CNT_N - 1], 1ull); } // renderers/ppm_image.zig:76 asserts col <= 255
         else v = (uint32_t)col;
-        if (v > 255u) v = 255u;
         q[c] = v;
     }
     if (rgb8) { rgb8[(size_t)i * 3u] = (uint8_t)q[0]; rgb8[(size_t)i * 3u + 1] = (uint8_t)q[1]; rgb8[(size_t)i * 3u + 2] = (uint8_t)q[2]; }
@@ -603,6 +621,24 @@ __global__ void pt_debug_eval(int fn, const float *in, float *out, uint32_t n, C
     }
 }
 
+// PT_FN_FILTER_BIT: the conservative filter's verdict for one (ray, sphere) pair — exactly the scan's arithmetic
+// (filter_ray_setup / filter_value, threshold from the host's filter_threshold) — beside the reference's
+// discriminant (sphere.zig:64-74).  The invariant the exact pass relies on: discriminant >= 0  =>  bit set.
+__global__ void pt_debug_filter_bit(const float *in, const float *thr, float *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = in + (size_t)i * 10;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const float a = vlen2(d);
+    const FilterRay fr = filter_ray_setup(o, d, a);
+    const float F = filter_value(fr, r[6], r[7], r[8]);
+    const V3 oc = vsub(o, v3(r[6], r[7], r[8]));
+    const float half_b = vdot(oc, d);
+    const float c = vlen2(oc) - r[9] * r[9];
+    out[(size_t)i * 2] = (thr[i] <= F) ? 1.0f : 0.0f; // v_cmp_le_f32 T, F
+    out[(size_t)i * 2 + 1] = half_b * half_b - a * c;
+}
+
 // cast_ray and scatter consume random draws: the debug variants take the draws from
 // the input record (ArrayRng) so that the oracle can be fed the same numbers.
 __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t n, Cam cam) {
@@ -678,8 +714,11 @@ struct ptgpu_ctx {
     float *d_tmp = nullptr; size_t tmp_bytes = 0;    // scratch image for host-pointer variants
     uint8_t *d_rec = nullptr; size_t rec_bytes = 0;  // scratch records for ptgpu_render_ppm
     unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;        // pinned: counters come back with an async copy, no staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    int resident[2][2] = {{0, 0}, {0, 0}};           // [det][multi]: workgroups per CU the occupancy query reports
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
+    uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
     pt_stats stats;
 };
 
@@ -714,6 +753,7 @@ extern "C" const char *ptgpu_strerror(int status) {
     case PT_ERR_SCENE_NOT_AVAILABLE: return "SceneNotAvailable";
     case PT_ERR_NO_SPACE: return "NoSpaceLeft";
     case PT_ERR_UNSUPPORTED: return "unsupported";
+    case PT_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -735,10 +775,28 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     memset(&ctx->stats, 0, sizeof ctx->stats);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, CNT_N * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counters, CNT_N * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
-    if (e != hipSuccess) { delete ctx; return PT_ERR_HIP; }
+    if (e == hipSuccess) {
+        // workgroups per CU each kernel variant can keep resident (the persistent grid's size)
+        int r = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
+    }
+    if (e != hipSuccess) {
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+        if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+        delete ctx;
+        return PT_ERR_HIP;
+    }
     const char *bpc = getenv("PTGPU_BLOCKS_PER_CU");
     if (bpc && atoi(bpc) > 0 && atoi(bpc) <= 8) ctx->blocks_per_cu = atoi(bpc);
     *out = ctx;
@@ -750,6 +808,7 @@ extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
@@ -773,6 +832,17 @@ extern "C" int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out) {
     return PT_OK;
 }
 
+extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    switch (which) {
+    case PT_LIMIT_PARTIAL_BYTES:
+        if (value < 4096) return PT_ERR_BAD_ARG;
+        ctx->partial_cap = value;
+        return PT_OK;
+    default: return PT_ERR_BAD_ARG;
+    }
+}
+
 // The filter threshold of sphere j (see the kernel comment): with c the centre,
 // cc = |c|^2, r2 = radius^2 and M = |o|^2 + cc, the kernel evaluates
 //   F = (oc.dh)^2 - |oc|^2 + cc + Keps*|o|^2     (dh = d/|d|, oc = o - c)
@@ -781,14 +851,15 @@ extern "C" int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out) {
 // The reference's float discriminant can only be >= 0 when the real-arithmetic one is
 // >= -~90*2^-24*M (rounding of both sides), Keps = 2^-16 = 256*2^-24.  Evaluated in
 // double and rounded toward -inf.
-static float filter_threshold(const pt_sphere &s) {
-    const double cx = s.cx, cy = s.cy, cz = s.cz, r = s.radius;
+static float filter_threshold_of(float cx_, float cy_, float cz_, float radius) {
+    const double cx = cx_, cy = cy_, cz = cz_, r = radius;
     const double cc = cx * cx + cy * cy + cz * cz;
     const double thr = cc - r * r - (double)kKeps * cc;
     float f = (float)thr;
     if ((double)f > thr) f = nextafterf(f, -INFINITY);
     return f;
 }
+static float filter_threshold(const pt_sphere &s) { return filter_threshold_of(s.cx, s.cy, s.cz, s.radius); }
 
 extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_t n) {
     if (!ctx || !spheres || n == 0) return PT_ERR_BAD_ARG;
@@ -811,21 +882,27 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
         kind[i] = s.kind;
     }
     for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, 0.f, INFINITY); // never a candidate
+    // Build the new tables aside and swap them in only when every step succeeded: a failure leaves the
+    // context with its previous scene intact (never half-updated).
+    void *fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void *src[5] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data()};
+    const size_t bytes[5] = {n_pad * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(uint32_t), n * sizeof(float)};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) {
+        e = hipMalloc(&fresh[i], bytes[i]);
+        if (e == hipSuccess) e = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        for (void *p : fresh) if (p) (void)hipFree(p);
+        ctx->last_hip = (int)e;
+        return (e == hipErrorOutOfMemory) ? PT_ERR_OOM : PT_ERR_HIP;
+    }
     void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius};
-    for (void *p : olds) if (p) HIP_TRY(ctx, hipFree(p));
-    ctx->d_filt = ctx->d_geom = ctx->d_mat = nullptr; ctx->d_kind = nullptr; ctx->d_inv_radius = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_filt, n_pad * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_geom, n * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_mat, n * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_kind, n * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_inv_radius, n * sizeof(float)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_filt, filt.data(), n_pad * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_mat, mat.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_kind, kind.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_inv_radius, inv_radius.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    ctx->d_filt = (float4 *)fresh[0]; ctx->d_geom = (float4 *)fresh[1]; ctx->d_mat = (float4 *)fresh[2];
+    ctx->d_kind = (uint32_t *)fresh[3]; ctx->d_inv_radius = (float *)fresh[4];
     ctx->nspheres = n;
     ctx->n_pad = n_pad;
+    for (void *p : olds) if (p) (void)hipFree(p);
     return PT_OK;
 }
 
@@ -870,12 +947,34 @@ static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, u
     return PT_OK;
 }
 
-extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream_) {
+// Device memory a render works in besides its inputs and output.
+struct Workspace {
+    unsigned long long *counters; // CNT_N
+    uint32_t *stack; size_t stack_bytes;
+    float *part; size_t part_bytes;
+};
+
+static void launch_megakernel(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+    if (det) {
+        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+    } else {
+        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+    }
+}
+
+// The render behind ptgpu_render_sum_device (workspace from hipMalloc, grown on demand).
+//
+// Chunk partials are bounded: when (chunks x pixel slots x 12 B) exceeds the partial buffer the slots are
+// traced in SEGMENTS, one megakernel launch + one pt_sum_chunks each, in stream order through the same
+// buffer.  A pixel's partials are still added in chunk order, so the result does not depend on the
+// segmentation (bit-identical to one launch); only the launch tails are paid once per segment.
+static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, hipStream_t stream) {
     uint32_t s0, s1, chunk;
     int rc = check_cfg(ctx, cfg, &s0, &s1, &chunk);
     if (rc != PT_OK) return rc;
     if (!d_rgb_sum) return PT_ERR_BAD_ARG;
-    hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t npix = cfg->idx_stop - cfg->idx_start;
     if (cfg->tile_pixels != 0) { // slots of this owner's tiles (the last one may be cut by idx_stop)
@@ -886,35 +985,41 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     memset(&ctx->stats, 0, sizeof ctx->stats);
     if (npix == 0 || s1 == s0) return PT_OK;
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
-    if ((uint64_t)npix * nchunks > 0xf0000000ull) return PT_ERR_BAD_ARG; // u32 item ids incl. the waves' last (overshooting) reservations
 
     const bool multi = ctx->n_pad > (uint32_t)kTile;
     const bool det = cfg->mode == 1;
     // persistent grid: as many workgroups per CU as the kernel variant can keep resident
-    int resident = 0;
-    {
-        hipError_t oe;
-        if (det) oe = multi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<true, true>, kBlock, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<true, false>, kBlock, 0);
-        else oe = multi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<false, true>, kBlock, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, pt_megakernel<false, false>, kBlock, 0);
-        if (oe != hipSuccess || resident <= 0) resident = 1;
-    }
-    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : resident;
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : ctx->resident[det ? 1 : 0][multi ? 1 : 0];
     const uint32_t grid = (uint32_t)(ctx->compute_units * bpc);
     const uint32_t total_threads = grid * kBlock;
-
-    float *part = nullptr;
-    if (nchunks == 1) {
-        part = d_rgb_sum; // one chunk: sums go straight to the frame
-    } else {
-        rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, (size_t)nchunks * npix * 3u * sizeof(float));
-        if (rc != PT_OK) return rc;
-        part = ctx->d_part;
-    }
     const size_t stack_need = (size_t)(cfg->rebounds ? cfg->rebounds : 1u) * total_threads * sizeof(uint32_t);
-    rc = ensure(ctx, (void **)&ctx->d_stack, &ctx->stack_bytes, stack_need);
-    if (rc != PT_OK) return rc;
+
+    Workspace ws{};
+    size_t part_avail; // bytes the partial buffer may take
+    {
+        rc = ensure(ctx, (void **)&ctx->d_stack, &ctx->stack_bytes, stack_need);
+        if (rc != PT_OK) return rc;
+        ws.counters = ctx->d_counters;
+        ws.stack = ctx->d_stack; ws.stack_bytes = ctx->stack_bytes;
+        ws.part = nullptr;
+        part_avail = (size_t)ctx->partial_cap;
+    }
+    // segment = pixel slots traced per launch
+    uint32_t seg = npix;
+    if (nchunks > 1) {
+        const uint64_t per_slot = (uint64_t)nchunks * 3u * sizeof(float);
+        const uint64_t fit = part_avail / per_slot;
+        if (fit < 64) return PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
+        if (fit < seg) seg = (uint32_t)(fit / 64u * 64u);
+        // u32 item ids incl. the waves' last (overshooting) reservations
+        const uint64_t max_items = 0xf0000000ull;
+        if ((uint64_t)seg * nchunks > max_items) seg = (uint32_t)(max_items / nchunks / 64u * 64u);
+        if (seg == 0) return PT_ERR_BAD_ARG;
+        const size_t part_need = (size_t)seg * per_slot;
+        rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, part_need);
+        if (rc != PT_OK) return rc;
+        ws.part = ctx->d_part; ws.part_bytes = ctx->part_bytes;
+    } else if ((uint64_t)npix > 0xf0000000ull) return PT_ERR_BAD_ARG;
 
     KParams P;
     P.cam = ctx->cam;
@@ -925,36 +1030,38 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     P.rebounds = cfg->rebounds;
     P.illum = cfg->illumination;
     P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
-    P.idx_start = cfg->idx_start; P.idx_stop = cfg->idx_stop; P.npix = npix;
+    P.idx_start = cfg->idx_start; P.idx_stop = cfg->idx_stop;
     P.tile_pixels = cfg->tile_pixels; P.tile_count = cfg->tile_count; P.tile_index = cfg->tile_index;
     P.direct = (nchunks == 1) ? 1u : 0u;
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
     P.filt = ctx->d_filt; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
-    P.part = part; P.stack = ctx->d_stack; P.counters = ctx->d_counters;
+    P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
+    P.stack = ws.stack; P.counters = ws.counters;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, CNT_N * sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (det) {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, P);
-    } else {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, P);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
-    if (nchunks > 1) {
-        const uint32_t n3 = npix * 3u;
-        hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)part, npix, nchunks, cfg->idx_start, cfg->idx_stop,
-                           cfg->tile_pixels, cfg->tile_count, cfg->tile_index, d_rgb_sum);
+    uint32_t nseg = 0;
+    for (uint32_t slot0 = 0; slot0 < npix; slot0 += seg, ++nseg) {
+        P.slot0 = slot0;
+        P.npix = std::min(seg, npix - slot0);
+        if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
+        launch_megakernel(det, multi, grid, stream, P);
         HIP_TRY(ctx, hipGetLastError());
+        if (slot0 == 0 && seg >= npix) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // one segment: ev0..ev1 is the megakernel alone
+        if (nchunks > 1) {
+            const uint32_t n3 = P.npix * 3u;
+            hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)ws.part, slot0, P.npix, nchunks,
+                               cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, d_rgb_sum);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
+    if (nseg > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // several segments: the span includes their (tiny) chunk sums
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ws.counters, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
-    unsigned long long h[CNT_N];
-    HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    const unsigned long long *h = ctx->h_counters;
     float ms01 = 0.f, ms02 = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms01, ctx->ev0, ctx->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(&ms02, ctx->ev0, ctx->ev2));
@@ -975,8 +1082,13 @@ extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, flo
     ctx->stats.flush_iters = h[CNT_FLUSH_ITERS];
     ctx->stats.kernel_ms = ms01;
     ctx->stats.total_ms = ms02;
+    ctx->stats.segments = nseg;
     if (h[CNT_NOT_UNIT]) return PT_ERR_DIRECTION_NOT_UNIT;
     return PT_OK;
+}
+
+extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream) {
+    return render_sum_impl(ctx, cfg, d_rgb_sum, (hipStream_t)stream);
 }
 
 extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum) {
@@ -1075,20 +1187,29 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_REFLECT: in_stride = 6; out_stride = 3; break;
     case PT_FN_LERP: in_stride = 9; out_stride = 4; break;
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
+    case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 2; break;
     default: return PT_ERR_UNSUPPORTED;
     }
     if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
     if (fn == PT_FN_CAST_RAY && !ctx->have_camera) return PT_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *d_in = nullptr, *d_out = nullptr;
+    float *d_in = nullptr, *d_out = nullptr, *d_thr = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_in, in_stride * n * sizeof(float)));
     hipError_t e = hipMalloc((void **)&d_out, out_stride * n * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(d_in); ctx->last_hip = (int)e; return PT_ERR_OOM; }
     int rc = PT_OK;
     e = hipMemcpy(d_in, in, in_stride * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && fn == PT_FN_FILTER_BIT) { // the per-sphere threshold ptgpu_set_scene would tabulate
+        std::vector<float> thr(n);
+        for (uint32_t i = 0; i < n; ++i) thr[i] = filter_threshold_of(in[(size_t)i * 10 + 6], in[(size_t)i * 10 + 7], in[(size_t)i * 10 + 8], in[(size_t)i * 10 + 9]);
+        e = hipMalloc((void **)&d_thr, n * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_thr, thr.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) {
         Cam cam = ctx->have_camera ? ctx->cam : Cam();
-        if (fn == PT_FN_SCENE_HIT_FILTERED) {
+        if (fn == PT_FN_FILTER_BIT) {
+            hipLaunchKernelGGL(pt_debug_filter_bit, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, (const float *)d_in, (const float *)d_thr, d_out, n);
+        } else if (fn == PT_FN_SCENE_HIT_FILTERED) {
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)
                 hipLaunchKernelGGL((pt_debug_scene_hit_filtered<true>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
@@ -1107,5 +1228,6 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     }
     if (e != hipSuccess) { ctx->last_hip = (int)e; rc = PT_ERR_HIP; }
     (void)hipFree(d_in); (void)hipFree(d_out);
+    if (d_thr) (void)hipFree(d_thr);
     return rc;
 }

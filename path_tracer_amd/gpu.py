@@ -78,6 +78,9 @@ class GpuContext:
         check(self._L.ptgpu_render_sum_device(self._h, C.byref(cfg), C.c_void_p(int(d_ptr)), C.c_void_p(int(stream))),
               "ptgpu_render_sum_device")
 
+    def set_limit(self, which, value):
+        check(self._L.ptgpu_set_limit(self._h, int(which), int(value)), "ptgpu_set_limit")
+
     def resolve_device(self, cfg, d_sum, d_records=0, d_rgb8=0, stream=0):
         cfg = self.as_config(cfg)
         check(self._L.ptgpu_resolve_device(self._h, C.byref(cfg), C.c_void_p(int(d_sum)), C.c_void_p(int(d_records)),

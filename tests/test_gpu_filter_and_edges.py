@@ -203,3 +203,58 @@ def test_colour_above_max_is_clamped_and_reported(gpu):
     assert e.value.status == _lib.PT_ERR_VALUE_EXCEEDS_MAX
     first = bytes(buf[img.header_size:img.header_size + 12])
     assert first[:3] == b"255" and first[11:12] == b"\n"        # top-left pixel is sky
+
+
+# ---- the filter invariant itself ---------------------------------------------------------------------------
+def _pairs(rng, n, o_scale, c_scale):
+    """(ray, sphere) pairs: random, aimed at the silhouette (tangent +- tiny), and origins ON the sphere."""
+    r = 10.0 ** rng.uniform(-3, 4, n) * rng.choice([1.0, 1.0, 1.0, -1.0], n)      # radii 1e-3 .. 1e4, some negative
+    c = rng.normal(0, 1, (n, 3)) * c_scale * rng.uniform(0, 1, (n, 1))
+    o = rng.normal(0, 1, (n, 3)) * o_scale * rng.uniform(0, 1, (n, 1))
+    kind = rng.integers(0, 4, n)
+    on = kind == 3                                                                 # bounce rays: origin on the surface
+    u = rng.normal(0, 1, (n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o[on] = c[on] + u[on] * np.abs(r[on, None])
+    to_c = c - o
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True) + 1e-30
+    axis = to_c / dist
+    perp = np.cross(axis, rng.normal(0, 1, (n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True) + 1e-30
+    eps = rng.choice([0.0, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4], (n, 1))
+    d = c + perp * np.abs(r[:, None]) * (1.0 + eps) - o                            # through the silhouette
+    rnd = rng.normal(0, 1, (n, 3))
+    d[kind == 0] = rnd[kind == 0]                                                  # anywhere
+    d[on] = rnd[on]
+    d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-30
+    d = d.astype(F)
+    # the megakernel's directions are unit vectors to ~1e-7 (vunit): renormalise in f32 as vec3.zig:61-64 does
+    inv = (F(1.0) / np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])).astype(F)
+    d = (d * inv[:, None]).astype(F)
+    return np.concatenate([o.astype(F), d, c.astype(F), r.astype(F)[:, None]], axis=1).astype(F)
+
+
+def test_filter_invariant_discriminant_nonneg_implies_candidate(gpu):
+    """The exact pass only ever sees the filter's candidates, and the parity tests compare final hits — a
+    dropped candidate that is not the closest hit would be invisible to them.  PT_FN_FILTER_BIT returns the
+    filter's verdict for a (ray, sphere) pair beside the reference's discriminant (sphere.zig:64-74): on
+    1.2e6 adversarial pairs (|o|, |c| up to the t_max = 1000 scale, radii 1e-3 .. 1e4, tangent rays, origins on
+    the surface) discriminant >= 0 must imply "candidate"."""
+    from path_tracer_amd import _lib
+    rng = np.random.default_rng(2024)
+    total = nonneg = cand = 0
+    for o_scale, c_scale in ((5.0, 12.0), (30.0, 30.0), (1000.0, 1000.0), (1000.0, 5.0), (0.0, 1000.0), (2000.0, 2000.0)):
+        pairs = _pairs(rng, 200000, o_scale, c_scale)
+        out = gpu.debug_eval(_lib.PT_FN_FILTER_BIT, pairs)
+        bit, disc = out[:, 0] == 1.0, out[:, 1]
+        # the device's discriminant is the reference's f32 arithmetic: cross-check against numpy float32
+        o, d, c, r = pairs[:, 0:3], pairs[:, 3:6], pairs[:, 6:9], pairs[:, 9]
+        oc = (o - c).astype(F)
+        a = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(F)
+        half_b = (oc[:, 0] * d[:, 0] + oc[:, 1] * d[:, 1] + oc[:, 2] * d[:, 2]).astype(F)
+        cc = ((oc[:, 0] * oc[:, 0] + oc[:, 1] * oc[:, 1] + oc[:, 2] * oc[:, 2]).astype(F) - r * r).astype(F)
+        np.testing.assert_array_equal(disc, (half_b * half_b - a * cc).astype(F))
+        bad = (disc >= 0) & ~bit
+        assert not bad.any(), (o_scale, c_scale, pairs[bad][:3], disc[bad][:3])
+        total += len(pairs); nonneg += int((disc >= 0).sum()); cand += int(bit.sum())
+    assert total >= 1_000_000 and nonneg > 100_000          # the invariant was exercised, not vacuous
+    assert cand < 0.9 * total                               # and the filter does reject
