@@ -41,6 +41,7 @@ enum {
     PT_ERR_SCENE_NOT_AVAILABLE = -7,/* errors.zig:2  UserError.SceneNotAvailable     */
     PT_ERR_NO_SPACE = -8,           /* caller buffer too small (Zig: NoSpaceLeft)    */
     PT_ERR_UNSUPPORTED = -9,        /* e.g. max_px_value != 255                      */
+    PT_ERR_SCRATCH_LIMIT = -10,     /* ptgpu_render_sum_device_noalloc: render does not fit its static scratch */
     PT_ERR_RCCL = -11               /* an RCCL call failed (ptgpu_multi_*)           */
 };
 
@@ -157,6 +158,18 @@ int ptgpu_set_camera(ptgpu_ctx *ctx, const pt_camera *cam);
  *   _host:   h_rgb_sum is host memory. */
 int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream);
 int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum);
+
+/* NO COUNTERPART IN THE REFERENCE.  ptgpu_render_sum_device for callers that cannot allocate device
+ * memory (code under HIP graph capture set-up, tight serving loops, harnesses that forbid hipMalloc):
+ * same arguments, same result bit for bit, but the kernels' working memory (counters, hit-id stack,
+ * chunk partial sums) is a static device array of ptgpu_noalloc_scratch_bytes() = 128 MiB per GPU
+ * inside the library instead of hipMalloc'ed buffers, and the call performs no hipMalloc / hipFree.
+ * The hit-id stack (rebounds x resident threads x 4 B) must fit, else PT_ERR_SCRATCH_LIMIT (depth 50
+ * takes 62.5 MiB; up to depth 102 fits); what remains holds the chunk partials, in as many segments
+ * as it takes (chunk = 0 needs none).  The scratch is shared by every context on the same GPU and
+ * keeps the last call's contents: calls that overlap on one GPU race — serialise them. */
+int ptgpu_render_sum_device_noalloc(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream);
+uint64_t ptgpu_noalloc_scratch_bytes(void);
 
 /* The resolve of renderers/ppm_image.zig:70-82 on the device: mean =
  * sum*(1/subpixels)*(1/rays_per_subsample), *max_px_value, truncating u8, the

@@ -21,6 +21,7 @@ PT_ERR_VALUE_EXCEEDS_MAX = -6
 PT_ERR_SCENE_NOT_AVAILABLE = -7
 PT_ERR_NO_SPACE = -8
 PT_ERR_UNSUPPORTED = -9
+PT_ERR_SCRATCH_LIMIT = -10
 PT_ERR_RCCL = -11
 
 PT_LIMIT_PARTIAL_BYTES = 0
@@ -71,7 +72,7 @@ assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104
 
 # every symbol include/ptgpu.h declares
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
-           "ptgpu_set_limit",
+           "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
            "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
            "ptgpu_abi_version"]
@@ -103,6 +104,8 @@ def load():
     L.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32]
     L.ptgpu_set_camera.argtypes = [vp, C.POINTER(pt_camera)]
     L.ptgpu_render_sum_device.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.ptgpu_render_sum_device_noalloc.argtypes = [vp, C.POINTER(pt_config), vp, vp]
+    L.ptgpu_noalloc_scratch_bytes.restype = C.c_uint64
     L.ptgpu_set_limit.argtypes = [vp, C.c_int, C.c_uint64]
     L.ptgpu_render_sum_host.argtypes = [vp, C.POINTER(pt_config), vp]
     L.ptgpu_render_mean_host.argtypes = [vp, C.POINTER(pt_config), vp]

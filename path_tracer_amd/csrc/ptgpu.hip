@@ -697,6 +697,14 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
 // ---------------------------------------------------------------------------
 // host side: context, uploads, launches
 // ---------------------------------------------------------------------------
+// Scratch of the no-allocation entry point (ptgpu_render_sum_device_noalloc): counters, hit-id stack and
+// chunk partials live in this file-scope device array instead of hipMalloc'ed buffers.  Every GPU the
+// library runs on holds its own copy at its own address (resolved once per context with
+// hipGetSymbolAddress, with that device current); host code only ever uses that resolved pointer.
+#define PT_SCRATCH_BYTES (128ull << 20)
+static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
+constexpr size_t kScratchCounters = 256; // bytes reserved for the CNT_N counters at the start of the scratch
+
 struct ptgpu_ctx {
     int device = -1;
     int compute_units = 0;
@@ -715,6 +723,7 @@ struct ptgpu_ctx {
     uint8_t *d_rec = nullptr; size_t rec_bytes = 0;  // scratch records for ptgpu_render_ppm
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;        // pinned: counters come back with an async copy, no staging
+    unsigned char *d_scratch = nullptr;              // this device's copy of `scratch` (hipGetSymbolAddress)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     int resident[2][2] = {{0, 0}, {0, 0}};           // [det][multi]: workgroups per CU the occupancy query reports
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
@@ -753,6 +762,7 @@ extern "C" const char *ptgpu_strerror(int status) {
     case PT_ERR_SCENE_NOT_AVAILABLE: return "SceneNotAvailable";
     case PT_ERR_NO_SPACE: return "NoSpaceLeft";
     case PT_ERR_UNSUPPORTED: return "unsupported";
+    case PT_ERR_SCRATCH_LIMIT: return "render does not fit the static scratch of the no-allocation entry point";
     case PT_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
     }
@@ -779,6 +789,8 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    // this device's address of the static scratch array (device `device` is current here)
+    if (e == hipSuccess) e = hipGetSymbolAddress((void **)&ctx->d_scratch, HIP_SYMBOL(scratch));
     if (e == hipSuccess) {
         // workgroups per CU each kernel variant can keep resident (the persistent grid's size)
         int r = 0;
@@ -788,7 +800,7 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
     }
-    if (e != hipSuccess) {
+    if (e != hipSuccess || !ctx->d_scratch) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -842,6 +854,8 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
     default: return PT_ERR_BAD_ARG;
     }
 }
+
+extern "C" uint64_t ptgpu_noalloc_scratch_bytes(void) { return PT_SCRATCH_BYTES; }
 
 // The filter threshold of sphere j (see the kernel comment): with c the centre,
 // cc = |c|^2, r2 = radius^2 and M = |o|^2 + cc, the kernel evaluates
@@ -964,13 +978,14 @@ static void launch_megakernel(bool det, bool multi, uint32_t grid, hipStream_t s
     }
 }
 
-// The render behind ptgpu_render_sum_device (workspace from hipMalloc, grown on demand).
+// The render behind both ptgpu_render_sum_device (workspace from hipMalloc, grown on demand) and
+// ptgpu_render_sum_device_noalloc (workspace carved out of the static scratch; allocates nothing).
 //
 // Chunk partials are bounded: when (chunks x pixel slots x 12 B) exceeds the partial buffer the slots are
 // traced in SEGMENTS, one megakernel launch + one pt_sum_chunks each, in stream order through the same
 // buffer.  A pixel's partials are still added in chunk order, so the result does not depend on the
 // segmentation (bit-identical to one launch); only the launch tails are paid once per segment.
-static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, hipStream_t stream) {
+static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, hipStream_t stream, bool noalloc) {
     uint32_t s0, s1, chunk;
     int rc = check_cfg(ctx, cfg, &s0, &s1, &chunk);
     if (rc != PT_OK) return rc;
@@ -996,7 +1011,15 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
 
     Workspace ws{};
     size_t part_avail; // bytes the partial buffer may take
-    {
+    if (noalloc) {
+        const size_t stack_off = kScratchCounters;
+        const size_t part_off = (stack_off + stack_need + 255u) & ~(size_t)255u;
+        if (part_off > PT_SCRATCH_BYTES) return PT_ERR_SCRATCH_LIMIT;
+        ws.counters = reinterpret_cast<unsigned long long *>(ctx->d_scratch);
+        ws.stack = reinterpret_cast<uint32_t *>(ctx->d_scratch + stack_off); ws.stack_bytes = stack_need;
+        ws.part = reinterpret_cast<float *>(ctx->d_scratch + part_off);
+        part_avail = PT_SCRATCH_BYTES - part_off;
+    } else {
         rc = ensure(ctx, (void **)&ctx->d_stack, &ctx->stack_bytes, stack_need);
         if (rc != PT_OK) return rc;
         ws.counters = ctx->d_counters;
@@ -1009,16 +1032,19 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     if (nchunks > 1) {
         const uint64_t per_slot = (uint64_t)nchunks * 3u * sizeof(float);
         const uint64_t fit = part_avail / per_slot;
-        if (fit < 64) return PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
+        if (fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
         if (fit < seg) seg = (uint32_t)(fit / 64u * 64u);
         // u32 item ids incl. the waves' last (overshooting) reservations
         const uint64_t max_items = 0xf0000000ull;
         if ((uint64_t)seg * nchunks > max_items) seg = (uint32_t)(max_items / nchunks / 64u * 64u);
         if (seg == 0) return PT_ERR_BAD_ARG;
         const size_t part_need = (size_t)seg * per_slot;
-        rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, part_need);
-        if (rc != PT_OK) return rc;
-        ws.part = ctx->d_part; ws.part_bytes = ctx->part_bytes;
+        if (noalloc) ws.part_bytes = part_need;
+        else {
+            rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, part_need);
+            if (rc != PT_OK) return rc;
+            ws.part = ctx->d_part; ws.part_bytes = ctx->part_bytes;
+        }
     } else if ((uint64_t)npix > 0xf0000000ull) return PT_ERR_BAD_ARG;
 
     KParams P;
@@ -1088,7 +1114,11 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
 }
 
 extern "C" int ptgpu_render_sum_device(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream) {
-    return render_sum_impl(ctx, cfg, d_rgb_sum, (hipStream_t)stream);
+    return render_sum_impl(ctx, cfg, d_rgb_sum, (hipStream_t)stream, false);
+}
+
+extern "C" int ptgpu_render_sum_device_noalloc(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream) {
+    return render_sum_impl(ctx, cfg, d_rgb_sum, (hipStream_t)stream, true);
 }
 
 extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum) {

@@ -78,6 +78,12 @@ class GpuContext:
         check(self._L.ptgpu_render_sum_device(self._h, C.byref(cfg), C.c_void_p(int(d_ptr)), C.c_void_p(int(stream))),
               "ptgpu_render_sum_device")
 
+    def render_sum_device_noalloc(self, cfg, d_ptr, stream=0):
+        """render_sum_device without any device allocation (static 128 MiB scratch inside the library)."""
+        cfg = self.as_config(cfg)
+        check(self._L.ptgpu_render_sum_device_noalloc(self._h, C.byref(cfg), C.c_void_p(int(d_ptr)), C.c_void_p(int(stream))),
+              "ptgpu_render_sum_device_noalloc")
+
     def set_limit(self, which, value):
         check(self._L.ptgpu_set_limit(self._h, int(which), int(value)), "ptgpu_set_limit")
 

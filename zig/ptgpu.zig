@@ -74,6 +74,9 @@ pub extern fn ptgpu_set_scene(ctx: *PtCtx, spheres: [*]const PtSphere, n: u32) c
 pub extern fn ptgpu_set_camera(ctx: *PtCtx, cam: *const PtCamera) c_int;
 pub extern fn ptgpu_render_ppm(ctx: *PtCtx, cfg: *const PtConfig, slice: [*]u8, slice_len: usize, header_size: u32, px_size: u32) c_int;
 pub extern fn ptgpu_render_sum_host(ctx: *PtCtx, cfg: *const PtConfig, rgb_sum: [*]f32) c_int;
+// no counterpart in the reference: the same render without any device allocation (static 128 MiB scratch per GPU)
+pub extern fn ptgpu_render_sum_device_noalloc(ctx: *PtCtx, cfg: *const PtConfig, d_rgb_sum: [*]f32, stream: ?*anyopaque) c_int;
+pub extern fn ptgpu_noalloc_scratch_bytes() u64;
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
 pub extern fn ptgpu_abi_version() u32;
 
