@@ -48,8 +48,12 @@ class Stats(C.Structure):
                 ("not_unit", C.c_uint64)]
 
 
+PRNG_XOROSHIRO128, PRNG_XOSHIRO256 = 0, 1   # pt_oracle.h: std.rand.DefaultPrng generations; the default is the demo-pinned one
+PRNG_KINDS = {"xoroshiro128": PRNG_XOROSHIRO128, "xoshiro256": PRNG_XOSHIRO256, None: PRNG_XOROSHIRO128}
+
+
 class ZigRng(C.Structure):
-    _fields_ = [("s", C.c_uint64 * 4)]
+    _fields_ = [("s", C.c_uint64 * 4), ("kind", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 def build(force=False):
@@ -83,6 +87,9 @@ def lib():
         L.orc_sample_radiance.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Camera), C.POINTER(Config), C.c_uint32,
                                           C.c_uint32, C.c_int, fp]
         L.orc_setup_scene.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(ZigRng)]
+        L.orc_setup_scene_prng.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(ZigRng)]
+        L.orc_zig_seed_kind.argtypes = [C.POINTER(ZigRng), C.c_uint64, C.c_uint32]
+        L.orc_zig_seed_kind.restype = None
         L.orc_scene_synthetic.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32]
         L.orc_camera_new.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Camera)]
         L.orc_camera_new.restype = None
@@ -148,11 +155,12 @@ def fptr(a):
 
 
 # ---- convenience wrappers --------------------------------------------------------
-def setup_scene(n_scene, seed=0):
-    """scene.zig:86-94 via main.zig:100-105; returns (spheres, zig rng state after)."""
+def setup_scene(n_scene, seed=0, prng=None):
+    """scene.zig:86-94 via main.zig:100-105; returns (spheres, zig rng state after).
+    prng: "xoroshiro128" (default: the generator behind the reference's images/demo.png) or "xoshiro256"."""
     buf = np.zeros(512, dtype=SPHERE_DTYPE)
     rng = ZigRng()
-    k = lib().orc_setup_scene(int(n_scene), int(seed), buf.ctypes.data, len(buf), C.byref(rng))
+    k = lib().orc_setup_scene_prng(int(n_scene), int(seed), PRNG_KINDS[prng], buf.ctypes.data, len(buf), C.byref(rng))
     if k < 0:
         raise ValueError("orc_setup_scene: %d" % k)
     return buf[:k].copy(), rng

@@ -77,23 +77,42 @@ uint64_t orc_splitmix64_next(uint64_t *state) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
-/* Zig 0.9.1 std/rand/Xoshiro256.zig seed(): four SplitMix64 outputs (recalled). */
-void orc_zig_seed(orc_zigrng *r, uint64_t seed) {
+/* std.rand.DefaultPrng.init(seed), two generations of Zig's std:
+ *   ORC_PRNG_XOROSHIRO128 — Xoroshiro128+ (rotations 55, 14, 36), seeded with two SplitMix64 outputs: the DefaultPrng
+ *     of the older std.  PINNED twice: by std's own "xoroshiro sequence" known-answer test (tests/test_oracle_kats.py)
+ *     and by the reference's images/demo.png — scene 21 built from this generator with seed 456 reproduces the
+ *     picture's 484 small spheres (tests/test_demo_pin.py); no other candidate does.
+ *   ORC_PRNG_XOSHIRO256 — Xoshiro256++ seeded with four SplitMix64 outputs: Zig 0.9.1's DefaultPrng as recalled
+ *     (pinned by the published xoshiro256++ vector only; no reference artefact made with it exists). */
+void orc_zig_seed_kind(orc_zigrng *r, uint64_t seed, uint32_t kind) {
     uint64_t s = seed;
-    for (int i = 0; i < 4; i++) r->s[i] = orc_splitmix64_next(&s);
+    memset(r, 0, sizeof *r);
+    r->kind = kind;
+    const int words = (kind == ORC_PRNG_XOSHIRO256) ? 4 : 2;
+    for (int i = 0; i < words; i++) r->s[i] = orc_splitmix64_next(&s);
 }
+void orc_zig_seed(orc_zigrng *r, uint64_t seed) { orc_zig_seed_kind(r, seed, ORC_PRNG_DEFAULT); }
 static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-/* xoshiro256++ (Blackman & Vigna), as Zig 0.9.1's DefaultPrng (recalled). */
 uint64_t orc_zig_next(orc_zigrng *r) {
     uint64_t *s = r->s;
-    const uint64_t res = rotl64(s[0] + s[3], 23) + s[0];
-    const uint64_t t = s[1] << 17;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl64(s[3], 45);
+    if (r->kind == ORC_PRNG_XOSHIRO256) { /* xoshiro256++ (Blackman & Vigna) */
+        const uint64_t res = rotl64(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl64(s[3], 45);
+        return res;
+    }
+    /* xoroshiro128+ (2016 constants), std/rand Xoroshiro128.next() */
+    const uint64_t s0 = s[0];
+    uint64_t s1 = s[1];
+    const uint64_t res = s0 + s1;
+    s1 ^= s0;
+    s[0] = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
+    s[1] = rotl64(s1, 36);
     return res;
 }
 /* Random.float(f32) of Zig 0.9.1: int(u32) = the low 4 bytes of one next();
@@ -575,7 +594,7 @@ int orc_render_sum_zig(const orc_sphere *sp, uint32_t n, const orc_camera *cam, 
     trace_ctx tc;
     trace_ctx_init(&tc, sp, n, cfg);
     orc_zigrng mat_state;
-    orc_zig_seed(&mat_state, 0); /* material.zig:15 */
+    orc_zig_seed_kind(&mat_state, 0, zr->kind); /* material.zig:15 */
     rng_t r_cam, r_mat;
     memset(&r_cam, 0, sizeof r_cam); r_cam.kind = RNG_ZIG; r_cam.z = zr;
     memset(&r_mat, 0, sizeof r_mat); r_mat.kind = RNG_ZIG; r_mat.z = &mat_state;
@@ -741,9 +760,13 @@ int orc_scene_21(orc_zigrng *r, orc_sphere *out, uint32_t cap) { /* scene.zig:52
     out[k++] = mk_sphere(4, 1, 0, 1.0f, 1, 0.7f, 0.6f, 0.5f, 0.0f);
     return (int)k;
 }
-int orc_setup_scene(int n_scene, uint64_t seed, orc_sphere *out, uint32_t cap, orc_zigrng *rng_after) { /* scene.zig:86-94, main.zig:100-105 */
+int orc_setup_scene(int n_scene, uint64_t seed, orc_sphere *out, uint32_t cap, orc_zigrng *rng_after) {
+    return orc_setup_scene_prng(n_scene, seed, ORC_PRNG_DEFAULT, out, cap, rng_after);
+}
+int orc_setup_scene_prng(int n_scene, uint64_t seed, uint32_t prng, orc_sphere *out, uint32_t cap, orc_zigrng *rng_after) { /* scene.zig:86-94, main.zig:100-105 */
     orc_zigrng r;
-    orc_zig_seed(&r, seed);
+    if (prng > ORC_PRNG_XOSHIRO256) return ORC_ERR_BAD_ARG;
+    orc_zig_seed_kind(&r, seed, prng);
     int k;
     if (n_scene == 18 || n_scene == 19 || n_scene == 20) k = orc_scene_18_19_20(out, cap);
     else if (n_scene == 21) k = orc_scene_21(&r, out, cap);
@@ -753,11 +776,11 @@ int orc_setup_scene(int n_scene, uint64_t seed, orc_sphere *out, uint32_t cap, o
 }
 /* BASELINE config 5 (not in the reference): n spheres = ground (r=1000) + n-1 small
  * ones, centres uniform in [-50,50] x {r} x [-50,50], r in U[0.05,0.3], materials
- * 80/15/5 % as scene.zig:63-72, drawn from the Zig-RNG emulation seeded `seed`. */
+ * 80/15/5 % as scene.zig:63-72, drawn from Xoshiro256++ seeded `seed`. */
 int orc_scene_synthetic(uint32_t n, uint64_t seed, orc_sphere *out, uint32_t cap) {
     if (cap < n || n < 1) return ORC_ERR_NO_SPACE;
     orc_zigrng r;
-    orc_zig_seed(&r, seed);
+    orc_zig_seed_kind(&r, seed, ORC_PRNG_XOSHIRO256); /* this scene's own definition (not a reference scene) */
     uint32_t k = 0;
     out[k++] = mk_sphere(0, -1000, 0, 1000, 0, 0.5f, 0.5f, 0.5f, 0.0f);
     while (k < n) {

@@ -12,10 +12,12 @@
  * reference's own test blocks hold for this path (tests/test_oracle_kats.py).  The
  * reference's tests pin NOTHING about image-level output or RNG streams, so:
  *   - image-level parity is "pinned by restatement + reference KATs only";
- *   - the Zig std pieces the path uses (std.rand Xoshiro256++/SplitMix64,
+ *   - the Zig std pieces the path uses (std.rand DefaultPrng/SplitMix64,
  *     Random.float(f32), math.pow) are restated from their published algorithms,
- *     recalled, NOT verifiable against a Zig build here: RNG-stream parity with a
- *     real reference binary is "parity unpinned".
+ *     recalled, NOT verifiable against a Zig build here.  The scene-construction stream IS
+ *     pinned by the one image the reference holds (images/demo.png: Xoroshiro128+, low 32
+ *     bits, the draw order of scene.zig:61-68; tests/test_demo_pin.py); the per-sample
+ *     jitter / scatter streams of a real reference binary remain "parity unpinned".
  *
  * PODs are layout-identical to include/ptgpu.h's (declared again here so that the
  * oracle depends on nothing of the product).
@@ -75,10 +77,15 @@ enum { ORC_OK = 0, ORC_ERR_BAD_ARG = -1, ORC_ERR_DIRECTION_NOT_UNIT = -5, ORC_ER
 
 enum { ORC_MODE_PHILOX = 0, ORC_MODE_DETERMINISTIC = 1, ORC_MODE_ZIG = 2 };
 
-/* ---- Zig 0.9.1 std.rand emulation (recalled; unpinned) ------------------ */
-typedef struct orc_zigrng { uint64_t s[4]; } orc_zigrng;
-void orc_zig_seed(orc_zigrng *r, uint64_t seed);     /* DefaultPrng.init(seed) */
-uint64_t orc_zig_next(orc_zigrng *r);                /* Xoshiro256.next()      */
+/* ---- Zig std.rand emulation ------------------------------------------------
+ * Two DefaultPrng generations (pt_oracle.c has the details): Xoroshiro128+ is pinned by std's own known-answer
+ * sequence AND by the reference's images/demo.png (scene 21, seed 456); Xoshiro256++ (Zig 0.9.1 as recalled) by
+ * its published vector only.  The default is the generator the reference's artefact was made with. */
+enum { ORC_PRNG_XOROSHIRO128 = 0, ORC_PRNG_XOSHIRO256 = 1, ORC_PRNG_DEFAULT = ORC_PRNG_XOROSHIRO128 };
+typedef struct orc_zigrng { uint64_t s[4]; uint32_t kind, pad_; } orc_zigrng;
+void orc_zig_seed(orc_zigrng *r, uint64_t seed);     /* DefaultPrng.init(seed), ORC_PRNG_DEFAULT */
+void orc_zig_seed_kind(orc_zigrng *r, uint64_t seed, uint32_t kind);
+uint64_t orc_zig_next(orc_zigrng *r);                /* Xoroshiro128.next() / Xoshiro256.next() */
 float orc_zig_float(orc_zigrng *r);                  /* Random.float(f32)      */
 uint64_t orc_splitmix64_next(uint64_t *state);
 
@@ -98,6 +105,7 @@ void orc_point_at(const float o[3], const float d[3], float t, float out[3]);
 int orc_scene_18_19_20(orc_sphere *out, uint32_t cap);                       /* scene.zig:32-50 */
 int orc_scene_21(orc_zigrng *r, orc_sphere *out, uint32_t cap);              /* scene.zig:52-84 */
 int orc_setup_scene(int n_scene, uint64_t seed, orc_sphere *out, uint32_t cap, orc_zigrng *rng_after); /* scene.zig:86-94 + main.zig:100-105 */
+int orc_setup_scene_prng(int n_scene, uint64_t seed, uint32_t prng, orc_sphere *out, uint32_t cap, orc_zigrng *rng_after);
 int orc_scene_synthetic(uint32_t n, uint64_t seed, orc_sphere *out, uint32_t cap); /* BASELINE config 5 */
 void orc_camera_new(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,
                     float aspect_ratio, float aperture, float focus_dist, orc_camera *out); /* camera.zig:48-97 */

@@ -26,7 +26,7 @@ class pthost_image(C.Structure):
                 ("blend_start", C.c_float * 3), ("blend_stop", C.c_float * 3)]
 
 
-HOST_EXPORTS = ["pthost_setup_scene", "pthost_scene_synthetic", "pthost_camera_new", "pthost_camera_preset",
+HOST_EXPORTS = ["pthost_setup_scene", "pthost_setup_scene_prng", "pthost_scene_synthetic", "pthost_camera_new", "pthost_camera_preset",
                 "pthost_image_new", "pthost_image_header", "pthost_rgb_to_ascii", "pthost_num_digits",
                 "pthost_col_num_to_string", "pthost_chunk_size", "pthost_render_scene_ppm", "pthost_filepath"]
 
@@ -43,6 +43,7 @@ def load_host():
     H = C.CDLL(HOST_LIB_PATH)
     fp = C.POINTER(C.c_float)
     H.pthost_setup_scene.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_uint32]
+    H.pthost_setup_scene_prng.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32]
     H.pthost_scene_synthetic.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32]
     H.pthost_camera_new.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(pt_camera)]
     H.pthost_camera_preset.argtypes = [C.c_int, C.c_float, C.POINTER(pt_camera)]
@@ -84,10 +85,14 @@ class Scene:
     def __init__(self):
         self.spheres = np.zeros(0, dtype=SPHERE_DTYPE)
 
-    def setupScene(self, seed, n):
-        """scene.setupScene(&prng.random(), n) with prng = DefaultPrng.init(seed) (main.zig:100-105)."""
+    PRNG = {"xoroshiro128": 0, "xoshiro256": 1, None: 0}
+
+    def setupScene(self, seed, n, prng=None):
+        """scene.setupScene(&prng.random(), n) with prng = DefaultPrng.init(seed) (main.zig:100-105).
+        prng: which std.rand.DefaultPrng generation — "xoroshiro128" (default: the one that reproduces the reference's
+        images/demo.png) or "xoshiro256" (Zig 0.9.1 as recalled); pt_host.h."""
         buf = np.zeros(512, dtype=SPHERE_DTYPE)
-        k = load_host().pthost_setup_scene(int(n), int(seed), buf.ctypes.data, len(buf))
+        k = load_host().pthost_setup_scene_prng(int(n), int(seed), self.PRNG[prng], buf.ctypes.data, len(buf))
         if k < 0:
             _raise(k, "setupScene")
         self.spheres = buf[:k].copy()

@@ -22,7 +22,7 @@ float Vec3f::dot(Vec3f o) const { return x * o.x + y * o.y + z * o.z; }
 Vec3f Vec3f::cross(Vec3f o) const { return make(y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x); }
 Vec3f Vec3f::elementwiseMul(Vec3f o) const { return make(x * o.x, y * o.y, z * o.z); }
 
-// ---- std.rand.DefaultPrng (Zig 0.9.1) -------------------------------------------------------
+// ---- std.rand.DefaultPrng ---------------------------------------------------------------------
 static uint64_t splitmix64(uint64_t &s) {
     s += 0x9e3779b97f4a7c15ULL;
     uint64_t z = s;
@@ -30,17 +30,27 @@ static uint64_t splitmix64(uint64_t &s) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
-DefaultPrng::DefaultPrng(uint64_t seed) {
+DefaultPrng::DefaultPrng(uint64_t seed, Prng kind) : kind_(kind) {
     uint64_t s = seed;
-    for (int i = 0; i < 4; ++i) s_[i] = splitmix64(s);
+    const int words = (kind == Prng::Xoshiro256) ? 4 : 2; // Xoshiro256.seed / Xoroshiro128.seed
+    for (int i = 0; i < 4; ++i) s_[i] = (i < words) ? splitmix64(s) : 0;
 }
 static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-uint64_t DefaultPrng::next() { // xoshiro256++
-    const uint64_t r = rotl(s_[0] + s_[3], 23) + s_[0];
-    const uint64_t t = s_[1] << 17;
-    s_[2] ^= s_[0]; s_[3] ^= s_[1]; s_[1] ^= s_[2]; s_[0] ^= s_[3];
-    s_[2] ^= t;
-    s_[3] = rotl(s_[3], 45);
+uint64_t DefaultPrng::next() {
+    if (kind_ == Prng::Xoshiro256) { // xoshiro256++
+        const uint64_t r = rotl(s_[0] + s_[3], 23) + s_[0];
+        const uint64_t t = s_[1] << 17;
+        s_[2] ^= s_[0]; s_[3] ^= s_[1]; s_[1] ^= s_[2]; s_[0] ^= s_[3];
+        s_[2] ^= t;
+        s_[3] = rotl(s_[3], 45);
+        return r;
+    }
+    const uint64_t s0 = s_[0]; // xoroshiro128+ (55, 14, 36)
+    uint64_t s1 = s_[1];
+    const uint64_t r = s0 + s1;
+    s1 ^= s0;
+    s_[0] = rotl(s0, 55) ^ s1 ^ (s1 << 14);
+    s_[1] = rotl(s1, 36);
     return r;
 }
 float DefaultPrng::float32() { // Random.float(f32): [1,2) from the top 23 bits of a u32, minus 1
@@ -101,7 +111,7 @@ int Scene::setupScene(DefaultPrng &r, int n) {
 }
 
 void Scene::sceneSynthetic(uint32_t n, uint64_t seed) {
-    DefaultPrng r(seed);
+    DefaultPrng r(seed, Prng::Xoshiro256); // this scene's own definition (not a reference scene)
     spheres.push_back(Sphere{Vec3f::make(0, -1000, 0), 1000, Material::lambertian(Vec3f::make(0.5f, 0.5f, 0.5f))});
     while (spheres.size() < n) {
         const float choose_mat = r.float32();
@@ -291,9 +301,13 @@ std::string filepath(size_t num_scene, const RayTracerConfig &cfg, const Image &
 using namespace pt;
 
 extern "C" int pthost_setup_scene(int num_scene, uint64_t seed, pt_sphere *out, uint32_t cap) {
-    DefaultPrng prng(seed); // main.zig:100
+    return pthost_setup_scene_prng(num_scene, seed, (uint32_t)Prng::Default, out, cap);
+}
+extern "C" int pthost_setup_scene_prng(int num_scene, uint64_t seed, uint32_t prng, pt_sphere *out, uint32_t cap) {
+    if (prng > (uint32_t)Prng::Xoshiro256) return PT_ERR_BAD_ARG;
+    DefaultPrng prng_(seed, (Prng)prng); // main.zig:100
     Scene scene;
-    const int rc = scene.setupScene(prng, num_scene);
+    const int rc = scene.setupScene(prng_, num_scene);
     if (rc != Ok) return rc;
     if (scene.spheres.size() > cap) return NoSpaceLeft;
     const std::vector<pt_sphere> f = scene.flatten();

@@ -35,15 +35,19 @@ struct Vec3f {
     Vec3f elementwiseMul(Vec3f o) const;
 };
 
-// std.rand.DefaultPrng of Zig 0.9.1 (Xoshiro256++ seeded through SplitMix64) and
-// Random.float(f32) — restated from the published algorithms (recalled; unpinned).
+// std.rand.DefaultPrng + Random.float(f32), restated from the published algorithms.  Zig's std had two
+// DefaultPrng generations: Xoroshiro128+ (older std) and Xoshiro256++ (0.9.1, as recalled).  The only image the
+// reference holds (images/demo.png: scene 21, seed 456) was made with Xoroshiro128+ — scene 21 built from it
+// reproduces the picture's small spheres, Xoshiro256++ does not (tests/test_demo_pin.py) — so that is the default.
+enum class Prng : uint32_t { Xoroshiro128 = 0, Xoshiro256 = 1, Default = Xoroshiro128 };
 class DefaultPrng {
 public:
-    explicit DefaultPrng(uint64_t seed);
+    explicit DefaultPrng(uint64_t seed, Prng kind = Prng::Default);
     uint64_t next();
     float float32();
 private:
     uint64_t s_[4];
+    Prng kind_;
 };
 
 // material.zig:174-189
@@ -146,7 +150,8 @@ std::string filepath(size_t num_scene, const RayTracerConfig &cfg, const Image &
 
 // ---- C view of the same host objects (for ctypes / tests) ------------------------------
 extern "C" {
-int pthost_setup_scene(int num_scene, uint64_t seed, pt_sphere *out, uint32_t cap);
+int pthost_setup_scene(int num_scene, uint64_t seed, pt_sphere *out, uint32_t cap);            // Prng::Default
+int pthost_setup_scene_prng(int num_scene, uint64_t seed, uint32_t prng, pt_sphere *out, uint32_t cap);
 int pthost_scene_synthetic(uint32_t n, uint64_t seed, pt_sphere *out, uint32_t cap);
 int pthost_camera_new(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov, float aspect_ratio,
                       float aperture, float focus_dist, pt_camera *out);

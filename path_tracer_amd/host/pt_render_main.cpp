@@ -14,7 +14,7 @@
 using namespace pt;
 
 static void usage() {
-    fprintf(stderr, "usage: pt_render [--scene 18|19|20|21] [--width W] [--spp N] [--depth D] [--seed S]\n"
+    fprintf(stderr, "usage: pt_render [--scene 18|19|20|21] [--width W] [--spp N] [--depth D] [--seed S] [--prng xoroshiro128|xoshiro256]\n"
                     "                 [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--out FILE]\n");
 }
 
@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
     unsigned width = 256, spp = 8, depth = 6, chunk = 0, illumination = PT_ILLUM_RADIANCE;
     unsigned long long seed = 42;
     bool deterministic = false;
+    Prng prng_kind = Prng::Default;
     std::string out;
     for (int i = 1; i < argc; ++i) {
         auto need = [&](const char *flag) { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", flag); exit(2); } return argv[++i]; };
@@ -35,6 +36,12 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--chunk")) chunk = (unsigned)strtoul(need("--chunk"), nullptr, 10);
         else if (!strcmp(argv[i], "--out")) out = need("--out");
         else if (!strcmp(argv[i], "--deterministic")) deterministic = true;
+        else if (!strcmp(argv[i], "--prng")) { // which std.rand.DefaultPrng generation builds scene 21 (pt_host.h)
+            const char *a = need("--prng");
+            if (!strcmp(a, "xoroshiro128")) prng_kind = Prng::Xoroshiro128;
+            else if (!strcmp(a, "xoshiro256")) prng_kind = Prng::Xoshiro256;
+            else { usage(); return 2; }
+        }
         else if (!strcmp(argv[i], "--aov")) { // the reference's commented-out colour functions (renderers/ppm_image.zig:64-65)
             const char *a = need("--aov");
             if (!strcmp(a, "normal")) illumination = PT_ILLUM_NORMAL;
@@ -47,7 +54,7 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     const Image img = Image::make(width, 16.0f / 9.0f, 255);              // main.zig:78
     const RayTracerConfig cfg{4, 0.1f, 1000.0f, depth, spp};               // main.zig:85-91
-    DefaultPrng prng(seed);                                               // main.zig:100
+    DefaultPrng prng(seed, prng_kind);                                    // main.zig:100
     Scene scene;
     int rc = scene.setupScene(prng, num_scene);                           // main.zig:105
     if (rc != Ok) { fprintf(stderr, "error: SceneNotAvailable\n"); return 1; }

@@ -192,11 +192,37 @@ def test_xoshiro256pp_kat(orc):
     """xoshiro256++ from state (1,2,3,4): the published reference sequence (also the vector in
     Zig's std/rand/Xoshiro256.zig test and in rand_xoshiro)."""
     r = orc.ZigRng()
+    r.kind = orc.PRNG_XOSHIRO256
     r.s[0], r.s[1], r.s[2], r.s[3] = 1, 2, 3, 4
     got = [orc.lib().orc_zig_next(C.byref(r)) for _ in range(10)]
     assert got == [41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205,
                    9973669472204895162, 14011001112246962877, 12406186145184390807, 15849039046786891736,
                    10450023813501588000]
+
+
+def test_xoroshiro128p_kat(orc):
+    """Xoroshiro128+ (rotations 55/14/36): the known-answer sequence of Zig std's own test "xoroshiro sequence"
+    (state 0xaeecf86f7878dd75, 0x01cd153642e72622) — the DefaultPrng generation behind images/demo.png."""
+    r = orc.ZigRng()
+    r.kind = orc.PRNG_XOROSHIRO128
+    r.s[0], r.s[1] = 0xaeecf86f7878dd75, 0x01cd153642e72622
+    got = [orc.lib().orc_zig_next(C.byref(r)) for _ in range(6)]
+    assert got == [0xb0ba0da5bb600397, 0x18a08afde614dccc, 0xa2635b956a31b929, 0xabe633c971efa045,
+                   0x9ac19f9706ca3cac, 0xf62b426578c1e3fb]
+
+
+def test_default_prng_generations(orc):
+    """DefaultPrng.init(seed): Xoroshiro128 takes two SplitMix64 words, Xoshiro256 four; the default is the
+    demo-pinned Xoroshiro128+ and the two build different scene-21 tables from the same seed."""
+    s = C.c_uint64(456)
+    words = [orc.lib().orc_splitmix64_next(C.byref(s)) for _ in range(4)]
+    a, b, d = orc.ZigRng(), orc.ZigRng(), orc.ZigRng()
+    orc.lib().orc_zig_seed_kind(C.byref(a), 456, orc.PRNG_XOROSHIRO128)
+    orc.lib().orc_zig_seed_kind(C.byref(b), 456, orc.PRNG_XOSHIRO256)
+    orc.lib().orc_zig_seed(C.byref(d), 456)
+    assert list(a.s) == words[:2] + [0, 0] and list(b.s) == words and (list(d.s), d.kind) == (list(a.s), a.kind)
+    t0, t1, td = (orc.setup_scene(21, 456, prng=k)[0] for k in ("xoroshiro128", "xoshiro256", None))
+    assert len(t0) == len(t1) == 488 and t0.tobytes() == td.tobytes() and t0.tobytes() != t1.tobytes()
 
 
 def test_splitmix64_kat(orc):

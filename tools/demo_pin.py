@@ -3,13 +3,16 @@
 
 The reference holds ONE rendered image (README.md:9: scene 21, 150 spp, depth 6, seed 456).  This
 script (CPU, test infrastructure: it uses the oracle) builds the scene-21 sphere table under a set
-of candidate generators and draw orders (scene.zig:57-74), renders each with the oracle at a quarter
-of the demo's size and reports the PSNR against the box-resampled demo.  A candidate that is the
+of candidate generators and draw orders (scene.zig:57-74), renders each with the oracle at configs[0]'s
+256x144 and reports the PSNR against the box-resampled demo.  A candidate that is the
 reference's generator must beat every other seed / variant by a wide margin.
 
     python tools/demo_pin.py [--spp 16] [--write-fixture]
 
---write-fixture stores the resampled demo (data only) as tests/golden/demo_resampled.npz.
+--write-fixture stores the demo box-resampled by 1/3 (data only: 223x398x3 uint8) as tests/golden/demo_398x223.npz;
+tests/test_demo_pin.py renders at the demo's own width (1193: the picture was NOT made at the prompt's default 256 —
+the v = (H - row + 1 + xi)/H quirk shifts a 144-row frame by 9 demo pixels, a 671-row frame by 2) and resamples
+its frame with the same operator.
 Reads /root/reference/images/demo.png, so it runs in the authoring container only.
 """
 import argparse
@@ -24,7 +27,7 @@ from oracle import oracle  # noqa: E402
 
 M64 = (1 << 64) - 1
 DEMO = "/root/reference/images/demo.png"
-W, H = 298, 167  # floor(298 / f32(16/9)) = 167; demo.png is 1193x669 = 4.003 x this
+W, H = 256, 144  # BASELINE configs[0]: the prompt's default width (main.zig:58); demo.png is 1193x669 = 4.66 x this
 
 
 def rotl(x, k):
@@ -147,8 +150,11 @@ def scene21(rnd, order="ref"):
     return sp
 
 
-def demo_resampled():
-    """Box-resample demo.png (1193x669) onto the W x H pixel grid: each target pixel is the area-weighted mean of the
+FIX_W, FIX_H = 398, 223  # the fixture: demo.png (1193x669) box-resampled by ~1/3
+
+
+def demo_resampled(W=W, H=H):
+    """Box-resample demo.png (1193x669) onto a W x H pixel grid: each target pixel is the area-weighted mean of the
     source pixels it covers."""
     from PIL import Image
     src = np.asarray(Image.open(DEMO).convert("RGB"), dtype=np.float64)
@@ -165,7 +171,7 @@ def demo_resampled():
         return Wm
 
     Wy, Wx = weights(sh, H), weights(sw, W)
-    return np.einsum("ij,jkc,lk->ilc", Wy, src, Wx)
+    return np.einsum("lk,ikc->ilc", Wx, np.einsum("ij,jkc->ikc", Wy, src))   # rows, then columns
 
 
 def render(spheres, spp, seed=1):
@@ -190,13 +196,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--write-fixture", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="only write the fixture")
     args = ap.parse_args()
     oracle.build()
     demo = demo_resampled()
     if args.write_fixture:
-        path = os.path.join(ROOT, "tests", "golden", "demo_resampled.npz")
-        np.savez_compressed(path, rgb=np.round(demo * 16).astype(np.uint16), scale=16, width=W, height=H)
+        path = os.path.join(ROOT, "tests", "golden", "demo_398x223.npz")
+        np.savez_compressed(path, rgb=np.clip(np.round(demo_resampled(FIX_W, FIX_H)), 0, 255).astype(np.uint8),
+                            src_size=np.array([1193, 669]))
         print("wrote", path)
+    if args.no_search:
+        return
     ground = np.zeros((H, W), dtype=bool)
     ground[H // 3:, :] = True  # below the horizon: where the 484 small spheres are
 
