@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the path-tracing hot path on MI355X.
 
-A "step" = one full render of BASELINE config 3 per GPU: scene 21 (488 spheres), 1920x1080,
-1024 paths per pixel (subpixels 4 x rays_per_subsample 256), depth 50, seed 456, with the
-scene/camera already resident in HBM and the fp32 radiance sums left in HBM.
-N > 1 GPUs: weak scaling by sample-range split — rank g traces samples [g*1024, (g+1)*1024) of a
-frame of N*1024 paths per pixel, then ONE RCCL reduce(SUM) of the fp32 sum buffers to rank 0 (inside
-the timed region).  value = paths traced by all ranks / max-over-ranks wall time.
+A "step" = one full render of BASELINE configs[2]: scene 21 (488 spheres), 1920x1080, 1024 paths per
+pixel (subpixels 4 x rays_per_subsample 256), depth 50, seed 456, with the scene/camera already
+resident in HBM and the fp32 radiance sums left in HBM.
+N > 1 GPUs: STRONG scaling of that same frame (BASELINE's metric: "scene 21 1080p, 1/2/4/8 GPUs") by
+sample-range split — rank g traces samples [g*1024/N, (g+1)*1024/N) of every pixel, then ONE RCCL
+reduce(SUM) of the fp32 sum buffers to rank 0 (inside the timed region).  `--weak` keeps the per-GPU
+work fixed instead (N x 1024 paths per pixel).  value = paths traced by all ranks / max-over-ranks
+wall time.
 
 Rank 0 prints one JSON line (contract in the task statement) with `roofline` (FP32 VALU) and,
 at N = 1, `cpu_baseline` (the oracle's C restatement timed on the host cores).
@@ -32,12 +34,18 @@ def algorithmic_flops(paths, rays, nspheres):
     return rays * nspheres * 18.0 + rays * 60.0 + paths * 40.0
 
 
+def executed_flops(paths, rays, nspheres):
+    """What the shipped kernel executes per ray-sphere test: 7 FMA + 1 compare (15 FLOP) on every lane; the exact
+    test runs on the filter's survivors only (inside the per-ray term)."""
+    return rays * nspheres * 15.0 + rays * 60.0 + paths * 40.0
+
+
 def cpu_baseline(width, depth, seed):
     """The oracle (C restatement of the reference algorithm, reference's thread split) on a bounded
     sample of the same workload: scene 21 at the same resolution and depth, 32 paths per pixel
     (subpixels 4 x rays_per_subsample 8) instead of 1024 — the rate does not depend on spp."""
     from oracle import oracle
-    oracle.build()
+    oracle.select_native()  # -O3 -march=native -ffp-contract=off, built on THIS box (the ReleaseFast stand-in of BASELINE.md)
     allowed = sorted(os.sched_getaffinity(0))
     cores = min(16, len(allowed))              # the GPU box's CPU share for one GPU is 16
     os.sched_setaffinity(0, set(allowed[:cores]))
@@ -55,8 +63,8 @@ def cpu_baseline(width, depth, seed):
     assert rc == 0
     return {"value": st.paths / dt, "unit": "paths/s", "cores": cores, "threads": threads, "kind": "port",
             "mrays_per_s": st.rays / dt * 1e-6, "seconds": dt,
-            "sample": "scene 21 %dx%d depth %d, 32 paths/pixel (%d paths, %d rays), oracle C restatement (gcc -O2, "
-                      "no FMA contraction), contiguous ceil(P/T) pixel chunks over T=%d pthreads pinned to %d cores"
+            "sample": "scene 21 %dx%d depth %d, 32 paths/pixel (%d paths, %d rays), oracle C restatement (gcc -O3 -march=native "
+                      "-ffp-contract=off, built on this box), contiguous ceil(P/T) pixel chunks over T=%d pthreads pinned to %d cores"
                       % (img.width, img.height, depth, st.paths, st.rays, threads, cores)}
 
 
@@ -69,14 +77,19 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="rays_per_subsample per GPU (x4 subpixels = paths/pixel)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=456)
-    ap.add_argument("--chunk", type=int, default=16, help="samples per GPU work item")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="samples per GPU work item; 0 = 16 on one GPU (and for --weak), max(4, 16/N) when N ranks share one frame "
+                         "(a rank's launch is N times shorter, so its tail must be: measured at 128 samples/rank, chunk 4/8/16/32 = "
+                         "51.1/51.7/52.5/54.7 ms against 50.95 ideal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spheres", type=int, default=0,
                     help="0 (default) = scene 21, the headline config; N > 0 = the synthetic random-sphere scene of N spheres "
                          "(BASELINE configs[4] uses 100000 with --spp 64 --split tiles)")
     ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
-                    help="multi-GPU partition: sample ranges (weak scaling: every rank traces 4 x spp paths per pixel) or "
-                         "interleaved 256-pixel tiles of ONE frame of 4 x spp paths per pixel (strong scaling)")
+                    help="multi-GPU partition of the frame: sample ranges of every pixel, or interleaved 256-pixel tiles")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling (sample split only): every rank traces 4 x spp paths per pixel of a frame of N x 4 x spp; "
+                         "default is strong scaling: ONE frame of 4 x spp paths per pixel shared by the N ranks")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="development only: run the N>1 plumbing on ONE GPU (all ranks on cuda:0, gloo all_reduce "
                          "instead of the RCCL reduce); the JSON line is marked and is not a benchmark result")
@@ -101,8 +114,11 @@ def main():
     from path_tracer_amd.gpu import GpuContext
 
     img = host.Image(args.width)
-    # sample split = weak scaling: N ranks trace N x (4 x spp) paths per pixel in total; tile split = one frame
-    weak = args.split == "samples"
+    weak = args.weak
+    if args.chunk == 0:
+        args.chunk = 16 if (world == 1 or weak) else max(4, 16 // world)
+    if weak and args.split != "samples":
+        raise SystemExit("bench.py: --weak needs --split samples")
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=args.spp * (world if weak else 1), rebounds=args.depth)
     scene = host.Scene().sceneSynthetic(args.spheres, 1) if args.spheres > 0 else host.Scene().setupScene(args.seed, 21)
     camera = host.Camera.preset(21, img.aspect_ratio)
@@ -167,7 +183,7 @@ def main():
                                    % (("BASELINE configs[2]: " if headline else "") + scene_name, img.width, img.height,
                                       4 * args.spp, "GPU" if weak else "frame", args.spp, args.depth),
                        "parallelism": "1 GPU" if world == 1 else
-                                      ("sample-range split x%d" if weak else "interleaved 256-pixel tile split x%d") % world
+                                      ("sample-range split x%d" if args.split == "samples" else "interleaved 256-pixel tile split x%d") % world
                                       + " + RCCL reduce(SUM) of fp32 sums",
                        "chunk": args.chunk, "global_paths_per_pixel": 4 * args.spp * (world if weak else 1)},
             "mrays_per_s": all_rays / dt_max * 1e-6,
@@ -176,8 +192,13 @@ def main():
                          "frac": achieved / PEAK_FP32_VALU, "traffic": None,
                          "kernel": "pt_megakernel", "kernel_ms": k_ms,
                          "flops_per_launch": flops_per_launch,
-                         "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d); algorithmic FLOPs = "
-                                 "18/ray-sphere test + 60/ray + 40/path over the device-counted rays of rank 0's launch"},
+                         "basis": "algorithmic",
+                         "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph) / (k_ms * 1e-3) / PEAK_FP32_VALU,
+                         "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d). `achieved`/`frac` price the "
+                                 "ALGORITHMIC work of the reference's scan: 18 FLOP/ray-sphere test + 60/ray + 40/path over the "
+                                 "device-counted rays of rank 0's launch — an algorithmic-work rate, not hardware utilisation. "
+                                 "`executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP); "
+                                 "issue-slot utilisation from the SQ counters is in profiles/"},
         }
         if args.rehearse_gloo:
             out["rehearsal"] = "all ranks on ONE GPU over gloo: plumbing check only, not a benchmark result"

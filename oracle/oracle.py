@@ -68,6 +68,15 @@ def build(force=False):
 _lib = None
 
 
+def select_native():
+    """bench.py's cpu_baseline leg only: build the same source with -O3 -march=native -ffp-contract=off ON THE BOX THAT
+    RUNS IT (oracle/Makefile target libptoracle_native.so; the same IEEE operations, so the same bits) and use it."""
+    global _SO, _lib
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "libptoracle_native.so"])  # -B: never reuse a copy built on another host
+    _SO, _lib = os.path.join(_HERE, "libptoracle_native.so"), None
+    return _SO
+
+
 def lib():
     global _lib
     if _lib is None:
