@@ -15,8 +15,8 @@
  *     the library owns every device buffer it allocates (freed by ptgpu_destroy);
  *   - every entry point returns an int status: PT_OK (0) or a negative PT_ERR_*;
  *   - one context drives one GPU; a context is not re-entrant (one host thread at a
- *     time per context); multi-GPU = one process (or context) per GPU, see
- *     INTEGRATION.md;
+ *     time per context); multi-GPU = ptgpu_multi_* below (one process, all GPUs of the
+ *     node) or one process per GPU with the caller's own collective, see INTEGRATION.md;
  *   - there is NO CPU fallback: without a usable gfx950 device ptgpu_create fails.
  */
 #ifndef PTGPU_H
@@ -217,6 +217,42 @@ enum {
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);
+
+/* ---- multi-GPU: the GPUs of one node behind one handle ---------------------------------
+ * Replaces the reference's thread block, main.zig:142-165 (T threads over contiguous pixel chunks of
+ * multithreading.zig:40-44, then join): one host thread per GPU drives that GPU's own context and
+ * stream, then ONE exchange step — an RCCL reduce(SUM) of the fp32 frame sums to GPU 0 over xGMI.
+ *   PT_SPLIT_TILES    runs of cfg->tile_pixels pixels (0 = 256) dealt round-robin to the GPUs (large
+ *                     frames / scenes); other owners' pixels are 0, so the reduce assembles the frame
+ *                     exactly: bit-identical to one GPU;
+ *   PT_SPLIT_SAMPLES  GPU g traces samples [a + g*n/G, a + (g+1)*n/G) of every pixel, [a, a+n) being
+ *                     cfg's own sample range (high-spp frames); equal to one GPU up to the fp32 add
+ *                     order of the G partial frames.
+ * cfg must not itself be one owner's share (tile_count <= 1).  librccl is dlopen'ed at the first
+ * create with num_gpus > 1 (PT_ERR_RCCL if that or a collective fails); with one GPU no collective runs
+ * (PTGPU_MULTI_FORCE_RCCL=1 in the environment runs it anyway, for tests).  Not re-entrant. */
+typedef struct ptgpu_multi ptgpu_multi;
+enum { PT_SPLIT_TILES = 0, PT_SPLIT_SAMPLES = 1 };
+int ptgpu_multi_create(const int *devices /* NULL = 0..num_gpus-1 */, int num_gpus, ptgpu_multi **out);
+int ptgpu_multi_destroy(ptgpu_multi *m);
+int ptgpu_multi_num_gpus(const ptgpu_multi *m);
+int ptgpu_multi_uses_rccl(const ptgpu_multi *m);
+ptgpu_ctx *ptgpu_multi_ctx(ptgpu_multi *m, int gpu);            /* the single-GPU context of GPU `gpu` (borrowed) */
+int ptgpu_multi_set_scene(ptgpu_multi *m, const pt_sphere *spheres, uint32_t n); /* replicated on every GPU */
+int ptgpu_multi_set_camera(ptgpu_multi *m, const pt_camera *cam);
+/* ptgpu_render_sum_host / ptgpu_render_ppm over all GPUs of the handle. */
+int ptgpu_multi_render_sum_host(ptgpu_multi *m, const pt_config *cfg, int split, float *h_rgb_sum);
+int ptgpu_multi_render_ppm(ptgpu_multi *m, const pt_config *cfg, int split, uint8_t *slice, size_t slice_len,
+                           uint32_t header_size, uint32_t px_size);
+/* The share GPU `gpu` of `num_gpus` renders (pure host arithmetic, no device needed): *out is the
+ * pt_config for ptgpu_render_sum_device on that GPU; *has_work = 0 when the share is empty (more GPUs
+ * than samples / tiles). */
+int ptgpu_multi_plan(const pt_config *cfg, int split, int num_gpus, int gpu, pt_config *out, int *has_work);
+/* Counters of the last render: of GPU `gpu`, or with gpu = -1 the totals (times: the slowest GPU's
+ * kernel_ms; total_ms includes the reduce). */
+int ptgpu_multi_get_stats(const ptgpu_multi *m, int gpu, pt_stats *out);
+double ptgpu_multi_reduce_ms(const ptgpu_multi *m);             /* HIP-event time of the last RCCL reduce on GPU 0 */
+int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResult_t of the last PT_ERR_RCCL */
 
 /* Limits.  PT_LIMIT_PARTIAL_BYTES (default 2 GiB): upper bound of the device buffer that holds the
  * chunk partial sums (chunks x pixels x 12 B).  A render that needs more is traced in segments of

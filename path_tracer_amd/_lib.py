@@ -25,6 +25,7 @@ PT_ERR_SCRATCH_LIMIT = -10
 PT_ERR_RCCL = -11
 
 PT_LIMIT_PARTIAL_BYTES = 0
+PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
@@ -75,7 +76,10 @@ EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera
            "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
            "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
-           "ptgpu_abi_version"]
+           "ptgpu_abi_version",
+           "ptgpu_multi_create", "ptgpu_multi_destroy", "ptgpu_multi_num_gpus", "ptgpu_multi_uses_rccl", "ptgpu_multi_ctx",
+           "ptgpu_multi_set_scene", "ptgpu_multi_set_camera", "ptgpu_multi_render_sum_host", "ptgpu_multi_render_ppm",
+           "ptgpu_multi_plan", "ptgpu_multi_get_stats", "ptgpu_multi_reduce_ms", "ptgpu_multi_last_rccl_error"]
 
 
 class PtGpuError(RuntimeError):
@@ -118,6 +122,21 @@ def load():
     L.ptgpu_last_hip_error.argtypes = [vp]
     L.ptgpu_device_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.ptgpu_abi_version.restype = C.c_uint32
+    L.ptgpu_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.ptgpu_multi_destroy.argtypes = [vp]
+    L.ptgpu_multi_num_gpus.argtypes = [vp]
+    L.ptgpu_multi_uses_rccl.argtypes = [vp]
+    L.ptgpu_multi_ctx.argtypes = [vp, C.c_int]
+    L.ptgpu_multi_ctx.restype = vp
+    L.ptgpu_multi_set_scene.argtypes = [vp, vp, C.c_uint32]
+    L.ptgpu_multi_set_camera.argtypes = [vp, C.POINTER(pt_camera)]
+    L.ptgpu_multi_render_sum_host.argtypes = [vp, C.POINTER(pt_config), C.c_int, vp]
+    L.ptgpu_multi_render_ppm.argtypes = [vp, C.POINTER(pt_config), C.c_int, vp, C.c_size_t, C.c_uint32, C.c_uint32]
+    L.ptgpu_multi_plan.argtypes = [C.POINTER(pt_config), C.c_int, C.c_int, C.c_int, C.POINTER(pt_config), C.POINTER(C.c_int)]
+    L.ptgpu_multi_get_stats.argtypes = [vp, C.c_int, C.POINTER(pt_stats)]
+    L.ptgpu_multi_reduce_ms.argtypes = [vp]
+    L.ptgpu_multi_reduce_ms.restype = C.c_double
+    L.ptgpu_multi_last_rccl_error.argtypes = [vp]
     _lib = L
     return L
 

@@ -27,23 +27,16 @@ def sample_range(total_samples, world, rank):
     return (rank * total_samples) // world, ((rank + 1) * total_samples) // world
 
 
-def plan(img, rt, seed, world, rank, split="samples", chunk=0, deterministic=False, tile_pixels=256,
-         samples_per_rank=None):
-    """The pt_config rank `rank` of `world` renders.
-
-    samples_per_rank (weak scaling): each rank traces that many samples and the frame's total
-    becomes world*samples_per_rank (rt.rays_per_subsample is scaled up accordingly).
-    """
-    if split == "samples":
-        total = rt.subpixels * rt.rays_per_subsample
-        s0, s1 = sample_range(total, world, rank)
-        if s1 == s0:  # more ranks than samples: an empty range must not mean "all samples"
-            return None
-        return make_pt_config(img, rt, seed, deterministic=deterministic, sample_start=s0, sample_stop=s1, chunk=chunk)
-    if split == "tiles":
-        return make_pt_config(img, rt, seed, deterministic=deterministic, chunk=chunk, tile_pixels=tile_pixels,
-                              tile_count=world, tile_index=rank)
-    raise ValueError("split must be 'samples' or 'tiles'")
+def plan(img, rt, seed, world, rank, split="samples", chunk=0, deterministic=False, tile_pixels=256):
+    """The pt_config rank `rank` of `world` renders, or None when its share is empty (more ranks than samples/tiles).
+    The split itself is the library's (ptgpu_multi_plan, include/ptgpu.h): the one-process ptgpu_multi_* path and this
+    one-process-per-GPU path partition a frame identically."""
+    from .gpu import multi_plan
+    whole = make_pt_config(img, rt, seed, deterministic=deterministic, chunk=chunk,
+                           tile_pixels=tile_pixels if split == "tiles" else 0)
+    if split not in ("samples", "tiles"):
+        raise ValueError("split must be 'samples' or 'tiles'")
+    return multi_plan(whole, split, world, rank)
 
 
 def render_sum_distributed(render_into, img, rt, seed, split="samples", chunk=0, deterministic=False, tile_pixels=256,

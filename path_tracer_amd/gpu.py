@@ -119,3 +119,78 @@ class GpuContext:
         arch = C.create_string_buffer(64)
         check(self._L.ptgpu_device_info(self._h, C.byref(cu), C.byref(khz), arch, 64), "ptgpu_device_info")
         return {"compute_units": cu.value, "clock_khz": khz.value, "arch": arch.value.decode()}
+
+
+SPLITS = {"tiles": _lib.PT_SPLIT_TILES, "samples": _lib.PT_SPLIT_SAMPLES}
+
+
+def multi_plan(cfg, split, num_gpus, gpu):
+    """ptgpu_multi_plan: the pt_config GPU `gpu` of `num_gpus` renders, or None when its share is empty.  Pure host
+    arithmetic in the library (no device needed)."""
+    cfg = GpuContext.as_config(cfg)
+    out, has = pt_config(), C.c_int()
+    check(_lib.load().ptgpu_multi_plan(C.byref(cfg), SPLITS.get(split, split), int(num_gpus), int(gpu), C.byref(out), C.byref(has)),
+          "ptgpu_multi_plan")
+    return out if has.value else None
+
+
+class MultiGpu:
+    """ptgpu_multi_*: all GPUs of one node from one process — one host thread, context and stream per GPU and an
+    RCCL reduce(SUM) of the fp32 sums to GPU 0 (replaces the thread block of main.zig:142-165)."""
+
+    def __init__(self, num_gpus=1, devices=None):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        dev = (C.c_int * num_gpus)(*devices) if devices is not None else None
+        check(self._L.ptgpu_multi_create(dev, int(num_gpus), C.byref(self._h)), "ptgpu_multi_create")
+        self.num_gpus = self._L.ptgpu_multi_num_gpus(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.ptgpu_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self):
+        return bool(self._L.ptgpu_multi_uses_rccl(self._h))
+
+    def set_scene(self, spheres):
+        sp = np.ascontiguousarray(spheres, dtype=_lib.SPHERE_DTYPE)
+        check(self._L.ptgpu_multi_set_scene(self._h, sp.ctypes.data, len(sp)), "ptgpu_multi_set_scene")
+
+    def set_camera(self, cam):
+        c = pt_camera()
+        C.memmove(C.byref(c), C.byref(cam), C.sizeof(pt_camera))
+        check(self._L.ptgpu_multi_set_camera(self._h, C.byref(c)), "ptgpu_multi_set_camera")
+
+    def render_sum(self, cfg, split="samples"):
+        cfg = GpuContext.as_config(cfg)
+        out = np.zeros((cfg.height, cfg.width, 3), dtype=np.float32)
+        check(self._L.ptgpu_multi_render_sum_host(self._h, C.byref(cfg), SPLITS[split], out.ctypes.data), "ptgpu_multi_render_sum_host")
+        return out
+
+    def render_ppm(self, cfg, split, slice_, header_size, px_size):
+        cfg = GpuContext.as_config(cfg)
+        assert slice_.dtype == np.uint8 and slice_.flags["C_CONTIGUOUS"]
+        check(self._L.ptgpu_multi_render_ppm(self._h, C.byref(cfg), SPLITS[split], slice_.ctypes.data, slice_.size, int(header_size),
+                                             int(px_size)), "ptgpu_multi_render_ppm")
+
+    def stats(self, gpu=-1):
+        st = pt_stats()
+        check(self._L.ptgpu_multi_get_stats(self._h, int(gpu), C.byref(st)), "ptgpu_multi_get_stats")
+        return st
+
+    def reduce_ms(self):
+        return self._L.ptgpu_multi_reduce_ms(self._h)

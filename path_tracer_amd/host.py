@@ -28,7 +28,8 @@ class pthost_image(C.Structure):
 
 HOST_EXPORTS = ["pthost_setup_scene", "pthost_setup_scene_prng", "pthost_scene_synthetic", "pthost_camera_new", "pthost_camera_preset",
                 "pthost_image_new", "pthost_image_header", "pthost_rgb_to_ascii", "pthost_num_digits",
-                "pthost_col_num_to_string", "pthost_chunk_size", "pthost_render_scene_ppm", "pthost_filepath"]
+                "pthost_col_num_to_string", "pthost_chunk_size", "pthost_render_scene_ppm", "pthost_render_scene_ppm_multi",
+                "pthost_filepath"]
 
 _host = None
 
@@ -57,6 +58,8 @@ def load_host():
     H.pthost_chunk_size.restype = C.c_uint64
     H.pthost_render_scene_ppm.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+    H.pthost_render_scene_ppm_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
     H.pthost_filepath.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p,
                                   C.c_size_t]
     _host = H

@@ -261,29 +261,51 @@ int Image::rgbToAscii(Vec3f col, char *out, size_t cap) const {
 // ---- renderers/ppm_image.zig -----------------------------------------------------------------------
 namespace ppm_renderer {
 
-int render(const Config &cfg) {
-    if (!cfg.gpu || !cfg.camera || !cfg.img || !cfg.ray_tracer_config || !cfg.slice || !cfg.scene) return PT_ERR_BAD_ARG;
+static int to_pt_config(const Config &cfg, pt_config *c) {
+    if (!cfg.camera || !cfg.img || !cfg.ray_tracer_config || !cfg.slice || !cfg.scene) return PT_ERR_BAD_ARG;
     const Image &img = *cfg.img;
     const RayTracerConfig &rt = *cfg.ray_tracer_config;
+    memset(c, 0, sizeof *c);
+    c->width = (uint32_t)img.width; c->height = (uint32_t)img.height;
+    c->subpixels = rt.subpixels; c->rays_per_subsample = rt.rays_per_subsample;
+    c->rebounds = rt.rebounds; c->mode = cfg.deterministic ? 1u : 0u;
+    c->seed = cfg.seed; c->t_min = rt.t_min; c->t_max = rt.t_max;
+    c->blend_start[0] = img.blend_start.x; c->blend_start[1] = img.blend_start.y; c->blend_start[2] = img.blend_start.z;
+    c->blend_stop[0] = img.blend_stop.x; c->blend_stop[1] = img.blend_stop.y; c->blend_stop[2] = img.blend_stop.z;
+    c->idx_start = (uint32_t)cfg.istart; c->idx_stop = (uint32_t)cfg.istop;
+    c->chunk = cfg.chunk;
+    c->illumination = cfg.illumination;
+    c->max_px_value = (uint32_t)img.max_px_value;
+    c->tile_count = 1;
+    return PT_OK;
+}
+
+int render(const Config &cfg) {
+    if (!cfg.gpu) return PT_ERR_BAD_ARG;
+    pt_config c;
+    int rc = to_pt_config(cfg, &c);
+    if (rc != PT_OK) return rc;
     const std::vector<pt_sphere> sp = cfg.scene->flatten();
-    int rc = ptgpu_set_scene(cfg.gpu, sp.data(), (uint32_t)sp.size());
+    rc = ptgpu_set_scene(cfg.gpu, sp.data(), (uint32_t)sp.size());
     if (rc != PT_OK) return rc;
     const pt_camera cam = cfg.camera->flatten();
     rc = ptgpu_set_camera(cfg.gpu, &cam);
     if (rc != PT_OK) return rc;
+    return ptgpu_render_ppm(cfg.gpu, &c, cfg.slice, cfg.slice_len, (uint32_t)cfg.img->header_size, (uint32_t)cfg.img->px_size);
+}
+
+int renderMultiGpu(const Config &cfg, ptgpu_multi *multi, int split) {
+    if (!multi) return PT_ERR_BAD_ARG;
     pt_config c;
-    memset(&c, 0, sizeof c);
-    c.width = (uint32_t)img.width; c.height = (uint32_t)img.height;
-    c.subpixels = rt.subpixels; c.rays_per_subsample = rt.rays_per_subsample;
-    c.rebounds = rt.rebounds; c.mode = cfg.deterministic ? 1u : 0u;
-    c.seed = cfg.seed; c.t_min = rt.t_min; c.t_max = rt.t_max;
-    c.blend_start[0] = img.blend_start.x; c.blend_start[1] = img.blend_start.y; c.blend_start[2] = img.blend_start.z;
-    c.blend_stop[0] = img.blend_stop.x; c.blend_stop[1] = img.blend_stop.y; c.blend_stop[2] = img.blend_stop.z;
-    c.idx_start = (uint32_t)cfg.istart; c.idx_stop = (uint32_t)cfg.istop;
-    c.chunk = cfg.chunk;
-    c.illumination = cfg.illumination;
-    c.max_px_value = (uint32_t)img.max_px_value;
-    return ptgpu_render_ppm(cfg.gpu, &c, cfg.slice, cfg.slice_len, (uint32_t)img.header_size, (uint32_t)img.px_size);
+    int rc = to_pt_config(cfg, &c);
+    if (rc != PT_OK) return rc;
+    const std::vector<pt_sphere> sp = cfg.scene->flatten();
+    rc = ptgpu_multi_set_scene(multi, sp.data(), (uint32_t)sp.size());
+    if (rc != PT_OK) return rc;
+    const pt_camera cam = cfg.camera->flatten();
+    rc = ptgpu_multi_set_camera(multi, &cam);
+    if (rc != PT_OK) return rc;
+    return ptgpu_multi_render_ppm(multi, &c, split, cfg.slice, cfg.slice_len, (uint32_t)cfg.img->header_size, (uint32_t)cfg.img->px_size);
 }
 
 } // namespace ppm_renderer
@@ -379,6 +401,29 @@ extern "C" int pthost_render_scene_ppm(ptgpu_ctx *gpu, int num_scene, uint32_t w
     ppm_renderer::Config cfg{gpu, &camera, &img, 0, img.num_pixels, seed, &rt, slice, slice_len, &scene};
     cfg.deterministic = deterministic != 0;
     rc = ppm_renderer::render(cfg);
+    if (rc != Ok) return rc;
+    const std::string h = img.header();
+    memcpy(slice, h.data(), h.size()); // main.zig:180-182
+    return Ok;
+}
+extern "C" int pthost_render_scene_ppm_multi(ptgpu_multi *multi, int split, int num_scene, uint32_t width, uint32_t subpixels,
+                                             uint32_t rays_per_subsample, uint32_t rebounds, uint64_t seed, int deterministic, uint32_t chunk,
+                                             uint8_t *slice, size_t slice_len) {
+    // main.zig:78-182 without the prompts, the thread block replaced by the GPUs of `multi`
+    const Image img = Image::make(width, 16.0f / 9.0f, 255);
+    const RayTracerConfig rt{subpixels, 0.1f, 1000.0f, rebounds, rays_per_subsample};
+    DefaultPrng prng(seed);
+    Scene scene;
+    int rc = scene.setupScene(prng, num_scene);
+    if (rc != Ok) return rc;
+    Camera camera;
+    rc = Camera::preset(num_scene, img.aspect_ratio, &camera);
+    if (rc != Ok) return rc;
+    if (slice_len < img.size) return NoSpaceLeft;
+    ppm_renderer::Config cfg{nullptr, &camera, &img, 0, img.num_pixels, seed, &rt, slice, slice_len, &scene};
+    cfg.deterministic = deterministic != 0;
+    cfg.chunk = chunk;
+    rc = ppm_renderer::renderMultiGpu(cfg, multi, split);
     if (rc != Ok) return rc;
     const std::string h = img.header();
     memcpy(slice, h.data(), h.size()); // main.zig:180-182

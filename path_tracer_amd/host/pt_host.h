@@ -141,6 +141,12 @@ struct Config {
 // their ASCII records into slice[header_size + idx*px_size ..].
 int render(const Config &cfg);
 
+// The multi-GPU counterpart of renderMultiThread (renderers/ppm_image.zig:91-129) and its thread
+// block (main.zig:142-165): the same Config (cfg.gpu is ignored), the GPUs of `multi` share the range
+// by interleaved tiles (PT_SPLIT_TILES) or by sample ranges (PT_SPLIT_SAMPLES) and the fp32 sums are
+// combined by one RCCL reduce before the single resolve.
+int renderMultiGpu(const Config &cfg, ptgpu_multi *multi, int split);
+
 } // namespace ppm_renderer
 
 // main.zig:194-203
@@ -171,6 +177,10 @@ uint64_t pthost_chunk_size(uint64_t num_pixels, uint64_t num_threads);
 // Whole-frame render of a preset scene through the renderer mirror; writes header + records.
 int pthost_render_scene_ppm(ptgpu_ctx *gpu, int num_scene, uint32_t width, uint32_t subpixels, uint32_t rays_per_subsample,
                             uint32_t rebounds, uint64_t seed, int deterministic, uint8_t *slice, size_t slice_len);
+// The same on all GPUs of `multi` (split: PT_SPLIT_TILES | PT_SPLIT_SAMPLES).
+int pthost_render_scene_ppm_multi(ptgpu_multi *multi, int split, int num_scene, uint32_t width, uint32_t subpixels,
+                                  uint32_t rays_per_subsample, uint32_t rebounds, uint64_t seed, int deterministic, uint32_t chunk,
+                                  uint8_t *slice, size_t slice_len);
 int pthost_filepath(uint64_t num_scene, uint32_t subpixels, uint32_t rays_per_subsample, uint32_t rebounds, uint32_t width,
                     uint64_t seed, char *buf, size_t cap);
 }

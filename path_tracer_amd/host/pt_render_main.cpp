@@ -15,11 +15,11 @@ using namespace pt;
 
 static void usage() {
     fprintf(stderr, "usage: pt_render [--scene 18|19|20|21] [--width W] [--spp N] [--depth D] [--seed S] [--prng xoroshiro128|xoshiro256]\n"
-                    "                 [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--out FILE]\n");
+                    "                 [--gpus N [--split tiles|samples]] [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--out FILE]\n");
 }
 
 int main(int argc, char **argv) {
-    int num_scene = 18, device = 0;               // prompt defaults: main.zig:50,58,63,66
+    int num_scene = 18, device = 0, gpus = 0, split = PT_SPLIT_TILES; // --gpus: the node's GPUs instead of main.zig's threads               // prompt defaults: main.zig:50,58,63,66
     unsigned width = 256, spp = 8, depth = 6, chunk = 0, illumination = PT_ILLUM_RADIANCE;
     unsigned long long seed = 42;
     bool deterministic = false;
@@ -33,6 +33,13 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--depth")) depth = (unsigned)strtoul(need("--depth"), nullptr, 10);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(need("--seed"), nullptr, 10);
         else if (!strcmp(argv[i], "--device")) device = atoi(need("--device"));
+        else if (!strcmp(argv[i], "--gpus")) gpus = atoi(need("--gpus"));
+        else if (!strcmp(argv[i], "--split")) {
+            const char *a = need("--split");
+            if (!strcmp(a, "tiles")) split = PT_SPLIT_TILES;
+            else if (!strcmp(a, "samples")) split = PT_SPLIT_SAMPLES;
+            else { usage(); return 2; }
+        }
         else if (!strcmp(argv[i], "--chunk")) chunk = (unsigned)strtoul(need("--chunk"), nullptr, 10);
         else if (!strcmp(argv[i], "--out")) out = need("--out");
         else if (!strcmp(argv[i], "--deterministic")) deterministic = true;
@@ -63,28 +70,43 @@ int main(int argc, char **argv) {
     if (rc != Ok) { fprintf(stderr, "error: SceneNotAvailable\n"); return 1; }
     std::vector<uint8_t> slice(img.size);                                 // main.zig:139
     ptgpu_ctx *gpu = nullptr;
-    rc = ptgpu_create(device, &gpu);
-    if (rc != PT_OK) { fprintf(stderr, "error: ptgpu_create: %s\n", ptgpu_strerror(rc)); return 1; }
-    ppm_renderer::Config rcfg{gpu, &camera, &img, 0, img.num_pixels, seed, &cfg, slice.data(), slice.size(), &scene};
+    ptgpu_multi *multi = nullptr;
+    ppm_renderer::Config rcfg{nullptr, &camera, &img, 0, img.num_pixels, seed, &cfg, slice.data(), slice.size(), &scene};
     rcfg.deterministic = deterministic;
     rcfg.chunk = chunk;
     rcfg.illumination = illumination;
-    rc = ppm_renderer::render(rcfg);                                      // main.zig:167-177
-    if (rc != PT_OK) { fprintf(stderr, "error: render: %s\n", ptgpu_strerror(rc)); ptgpu_destroy(gpu); return 1; }
     pt_stats st;
-    ptgpu_get_stats(gpu, &st);
+    double reduce_ms = 0.0;
+    if (gpus > 0) { // main.zig:142-165: "use the multi-threaded version" -> the GPUs of the node
+        rc = ptgpu_multi_create(nullptr, gpus, &multi);
+        if (rc != PT_OK) { fprintf(stderr, "error: ptgpu_multi_create(%d GPUs): %s\n", gpus, ptgpu_strerror(rc)); return 1; }
+        rc = ppm_renderer::renderMultiGpu(rcfg, multi, split);
+        if (rc != PT_OK) { fprintf(stderr, "error: render: %s\n", ptgpu_strerror(rc)); ptgpu_multi_destroy(multi); return 1; }
+        ptgpu_multi_get_stats(multi, -1, &st);
+        reduce_ms = ptgpu_multi_reduce_ms(multi);
+    } else {
+        rc = ptgpu_create(device, &gpu);
+        if (rc != PT_OK) { fprintf(stderr, "error: ptgpu_create: %s\n", ptgpu_strerror(rc)); return 1; }
+        rcfg.gpu = gpu;
+        rc = ppm_renderer::render(rcfg);                                  // main.zig:167-177
+        if (rc != PT_OK) { fprintf(stderr, "error: render: %s\n", ptgpu_strerror(rc)); ptgpu_destroy(gpu); return 1; }
+        ptgpu_get_stats(gpu, &st);
+    }
     const std::string header = img.header();                              // main.zig:180-182
     memcpy(slice.data(), header.data(), header.size());
     const std::string path = out.empty() ? filepath((size_t)num_scene, cfg, img, (size_t)seed) : out;
     FILE *f = fopen(path.c_str(), "wb");                                  // main.zig:187
-    if (!f) { fprintf(stderr, "error: cannot open %s\n", path.c_str()); ptgpu_destroy(gpu); return 1; }
+    if (!f) { fprintf(stderr, "error: cannot open %s\n", path.c_str()); if (gpu) ptgpu_destroy(gpu); if (multi) ptgpu_multi_destroy(multi); return 1; }
     fwrite(slice.data(), 1, slice.size(), f);
     fclose(f);
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "info: wrote %s\n", path.c_str());
     fprintf(stderr, "info: %llu paths, %llu rays, kernel %.2f ms: %.3e paths/s, %.1f Mrays/s\n", (unsigned long long)st.paths,
             (unsigned long long)st.rays, st.kernel_ms, st.paths / (st.kernel_ms * 1e-3), st.rays / (st.kernel_ms * 1e-3) * 1e-6);
+    if (multi) fprintf(stderr, "info: %d GPUs, %s split, slowest kernel %.2f ms, RCCL reduce %.3f ms\n", gpus,
+                       split == PT_SPLIT_TILES ? "tile" : "sample-range", st.kernel_ms, reduce_ms);
     fprintf(stderr, "info: Program took %.2f seconds\n", s);             // main.zig:191
-    ptgpu_destroy(gpu);
+    if (gpu) ptgpu_destroy(gpu);
+    if (multi) ptgpu_multi_destroy(multi);
     return 0;
 }

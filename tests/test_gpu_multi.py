@@ -1,0 +1,72 @@
+"""ptgpu_multi_* on the one GPU of the test box: the whole multi-GPU code path of the C ABI — per-GPU thread,
+context, stream and frame, the plan, and (with PTGPU_MULTI_FORCE_RCCL=1) a real RCCL communicator and
+ncclReduce — must reproduce the single-GPU entry points bit for bit.  N > 1 is the same code with more threads;
+its partition arithmetic is covered on CPU (tests/test_multi_plan_cpu.py, tests/test_distributed_cpu.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_multi_one_gpu_matches_single_gpu(gpu, force_rccl, monkeypatch):
+    from path_tracer_amd import host
+    from path_tracer_amd.gpu import MultiGpu
+    monkeypatch.setenv("PTGPU_MULTI_FORCE_RCCL", "1" if force_rccl else "0")
+    scene = host.Scene().setupScene(456, 21)
+    cam = host.Camera.preset(21)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(cam.pod)
+    img = host.Image(160)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=4, rebounds=50)
+    with MultiGpu(1) as m:
+        assert m.num_gpus == 1 and m.uses_rccl == force_rccl
+        m.set_scene(scene.spheres)
+        m.set_camera(cam.pod)
+        for kw in (dict(chunk=4), dict(chunk=4, istart=160 * 10, istop=160 * 50 + 7), dict(chunk=0, sample_start=3, sample_stop=11)):
+            cfg = host.make_pt_config(img, rt, seed=5, **kw)
+            want = gpu.render_sum(cfg)
+            for split in ("tiles", "samples"):
+                if split == "tiles" and kw.get("istart", 0) % 256:
+                    continue
+                got = m.render_sum(cfg, split)
+                np.testing.assert_array_equal(got, want)
+                st, one = m.stats(), gpu.stats()
+                assert (st.paths, st.rays) == (one.paths, one.rays) and m.stats(0).paths == st.paths
+        cfg = host.make_pt_config(img, rt, seed=5, chunk=4)
+        a, b = np.zeros(img.size, dtype=np.uint8), np.zeros(img.size, dtype=np.uint8)
+        gpu.render_ppm(cfg, a, img.header_size, img.px_size)
+        m.render_ppm(cfg, "samples", b, img.header_size, img.px_size)
+        np.testing.assert_array_equal(a, b)
+        if force_rccl:
+            assert m.reduce_ms() > 0.0
+
+
+def test_multi_rejects_bad_devices():
+    from path_tracer_amd import _lib
+    from path_tracer_amd._lib import PtGpuError
+    from path_tracer_amd.gpu import MultiGpu
+    with pytest.raises(PtGpuError) as e:
+        MultiGpu(2, devices=[0, 0])                      # one context per GPU
+    assert e.value.status == _lib.PT_ERR_BAD_ARG
+    with pytest.raises(PtGpuError) as e:
+        MultiGpu(1, devices=[99])
+    assert e.value.status == _lib.PT_ERR_NO_DEVICE
+
+
+def test_pt_render_cli_gpus_flag(tmp_path):
+    """pt_render --gpus 1 (renderMultiGpu, main.zig's "multi-threaded version") writes the same file as the single-GPU path."""
+    exe = os.path.join(ROOT, "path_tracer_amd", "pt_render")
+    args = ["--scene", "21", "--width", "96", "--spp", "3", "--depth", "12", "--seed", "456", "--chunk", "4"]
+    one, multi_t, multi_s = (str(tmp_path / n) for n in ("one.ppm", "mt.ppm", "ms.ppm"))
+    env = dict(os.environ, PTGPU_MULTI_FORCE_RCCL="1")
+    subprocess.run([exe] + args + ["--out", one], check=True, timeout=120, capture_output=True)
+    subprocess.run([exe] + args + ["--gpus", "1", "--split", "tiles", "--out", multi_t], check=True, timeout=300, capture_output=True, env=env)
+    r = subprocess.run([exe] + args + ["--gpus", "1", "--split", "samples", "--out", multi_s], check=True, timeout=300, capture_output=True, env=env)
+    assert b"RCCL reduce" in r.stderr
+    ref = open(one, "rb").read()
+    assert ref.startswith(b"P3\n96 54\n255\n") and open(multi_t, "rb").read() == ref and open(multi_s, "rb").read() == ref

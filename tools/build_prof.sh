@@ -4,5 +4,5 @@
 set -euo pipefail
 cd "$(dirname "$0")/../path_tracer_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -DPT_PHASE_TIMING -o ../libptgpu_prof.so ptgpu.hip
+  -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -DPT_PHASE_TIMING -o ../libptgpu_prof.so ptgpu.hip ptgpu_multi.cpp -ldl -pthread
 echo built libptgpu_prof.so

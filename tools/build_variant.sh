@@ -6,5 +6,5 @@ set -euo pipefail
 name=$1; shift
 cd "$(dirname "$0")/../path_tracer_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -o ../libptgpu_${name}.so ptgpu.hip
+  -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize "$@" -o ../libptgpu_${name}.so ptgpu.hip ptgpu_multi.cpp -ldl -pthread
 echo built libptgpu_${name}.so

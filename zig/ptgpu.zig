@@ -74,13 +74,24 @@ pub extern fn ptgpu_set_scene(ctx: *PtCtx, spheres: [*]const PtSphere, n: u32) c
 pub extern fn ptgpu_set_camera(ctx: *PtCtx, cam: *const PtCamera) c_int;
 pub extern fn ptgpu_render_ppm(ctx: *PtCtx, cfg: *const PtConfig, slice: [*]u8, slice_len: usize, header_size: u32, px_size: u32) c_int;
 pub extern fn ptgpu_render_sum_host(ctx: *PtCtx, cfg: *const PtConfig, rgb_sum: [*]f32) c_int;
+// ---- all GPUs of the node (replaces the thread block of main.zig:142-165) -----------------------
+pub const PtMulti = opaque {};
+pub const PT_SPLIT_TILES: c_int = 0;
+pub const PT_SPLIT_SAMPLES: c_int = 1;
+pub extern fn ptgpu_multi_create(devices: ?[*]const c_int, num_gpus: c_int, out: *?*PtMulti) c_int;
+pub extern fn ptgpu_multi_destroy(m: *PtMulti) c_int;
+pub extern fn ptgpu_multi_set_scene(m: *PtMulti, spheres: [*]const PtSphere, n: u32) c_int;
+pub extern fn ptgpu_multi_set_camera(m: *PtMulti, cam: *const PtCamera) c_int;
+pub extern fn ptgpu_multi_render_ppm(m: *PtMulti, cfg: *const PtConfig, split: c_int, slice: [*]u8, slice_len: usize, header_size: u32, px_size: u32) c_int;
+pub extern fn ptgpu_multi_render_sum_host(m: *PtMulti, cfg: *const PtConfig, split: c_int, rgb_sum: [*]f32) c_int;
+
 // no counterpart in the reference: the same render without any device allocation (static 128 MiB scratch per GPU)
 pub extern fn ptgpu_render_sum_device_noalloc(ctx: *PtCtx, cfg: *const PtConfig, d_rgb_sum: [*]f32, stream: ?*anyopaque) c_int;
 pub extern fn ptgpu_noalloc_scratch_bytes() u64;
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
 pub extern fn ptgpu_abi_version() u32;
 
-pub const Error = error{ NoGpu, BadArgument, HipFailure, OutOfMemory, DirectionIsNotUnitVector, ValueExceedsMaxValue, NoSpaceLeft, Unsupported };
+pub const Error = error{ NoGpu, BadArgument, HipFailure, OutOfMemory, DirectionIsNotUnitVector, ValueExceedsMaxValue, NoSpaceLeft, Unsupported, ScratchLimit, RcclFailure };
 
 fn check(rc: c_int) Error!void {
     return switch (rc) {
@@ -92,6 +103,8 @@ fn check(rc: c_int) Error!void {
         -6 => error.ValueExceedsMaxValue, // utils.zig:63-65
         -8 => error.NoSpaceLeft,
         -9 => error.Unsupported,
+        -10 => error.ScratchLimit,
+        -11 => error.RcclFailure,
         else => error.BadArgument,
     };
 }
@@ -142,23 +155,10 @@ pub fn flattenCamera(c: *const Camera) PtCamera {
     };
 }
 
-/// GPU replacement of renderers/ppm_image.zig:30 `render(cfg)`: same Config, same bytes
-/// written into `cfg.slice` at `header_size + idx * px_size` for idx in [istart, istop).
-/// `seed` keys the Philox streams (cfg.r, the sequential std.rand stream, is not used).
-pub fn render(cfg: RendererConfig, seed: u64) !void {
-    var gpu: ?*PtCtx = null;
-    try check(ptgpu_create(0, &gpu));
-    defer _ = ptgpu_destroy(gpu.?);
-
-    const flat = try flattenScene(cfg.allocator.*, cfg.scene);
-    defer cfg.allocator.free(flat);
-    try check(ptgpu_set_scene(gpu.?, flat.ptr, @intCast(u32, flat.len)));
-    const cam = flattenCamera(cfg.camera);
-    try check(ptgpu_set_camera(gpu.?, &cam));
-
+fn toPtConfig(cfg: RendererConfig, seed: u64) PtConfig {
     const img = cfg.img;
     const rt = cfg.ray_tracer_config;
-    const pc = PtConfig{
+    return PtConfig{
         .width = @intCast(u32, img.width),
         .height = @intCast(u32, img.height),
         .subpixels = rt.subpixels,
@@ -174,14 +174,49 @@ pub fn render(cfg: RendererConfig, seed: u64) !void {
         .idx_stop = @intCast(u32, cfg.istop),
         .sample_start = 0,
         .sample_stop = 0, // 0,0 = all subpixels * rays_per_subsample samples
-        .chunk = 64,
+        .chunk = 16,
         .max_px_value = @intCast(u32, img.max_px_value),
         .tile_pixels = 0,
         .tile_count = 1,
         .tile_index = 0,
         .illumination = 0,
     };
-    try check(ptgpu_render_ppm(gpu.?, &pc, cfg.slice.ptr, cfg.slice.len, @intCast(u32, img.header_size), @intCast(u32, img.px_size)));
+}
+
+/// GPU replacement of renderers/ppm_image.zig:30 `render(cfg)`: same Config, same bytes
+/// written into `cfg.slice` at `header_size + idx * px_size` for idx in [istart, istop).
+/// `seed` keys the Philox streams (cfg.r, the sequential std.rand stream, is not used).
+pub fn render(cfg: RendererConfig, seed: u64) !void {
+    var gpu: ?*PtCtx = null;
+    try check(ptgpu_create(0, &gpu));
+    defer _ = ptgpu_destroy(gpu.?);
+
+    const flat = try flattenScene(cfg.allocator.*, cfg.scene);
+    defer cfg.allocator.free(flat);
+    try check(ptgpu_set_scene(gpu.?, flat.ptr, @intCast(u32, flat.len)));
+    const cam = flattenCamera(cfg.camera);
+    try check(ptgpu_set_camera(gpu.?, &cam));
+
+    const pc = toPtConfig(cfg, seed);
+    try check(ptgpu_render_ppm(gpu.?, &pc, cfg.slice.ptr, cfg.slice.len, @intCast(u32, cfg.img.header_size), @intCast(u32, cfg.img.px_size)));
+}
+
+/// The multi-GPU counterpart of the `use_multithreaded_version` branch (main.zig:142-165): `num_gpus` GPUs
+/// share [istart, istop) by interleaved tiles (PT_SPLIT_TILES) or by sample ranges (PT_SPLIT_SAMPLES); the
+/// library spawns one host thread per GPU, reduces the fp32 sums over RCCL and resolves once.
+pub fn renderMultiGpu(cfg: RendererConfig, seed: u64, num_gpus: c_int, split: c_int) !void {
+    var multi: ?*PtMulti = null;
+    try check(ptgpu_multi_create(null, num_gpus, &multi));
+    defer _ = ptgpu_multi_destroy(multi.?);
+
+    const flat = try flattenScene(cfg.allocator.*, cfg.scene);
+    defer cfg.allocator.free(flat);
+    try check(ptgpu_multi_set_scene(multi.?, flat.ptr, @intCast(u32, flat.len)));
+    const cam = flattenCamera(cfg.camera);
+    try check(ptgpu_multi_set_camera(multi.?, &cam));
+
+    const pc = toPtConfig(cfg, seed);
+    try check(ptgpu_multi_render_ppm(multi.?, &pc, split, cfg.slice.ptr, cfg.slice.len, @intCast(u32, cfg.img.header_size), @intCast(u32, cfg.img.px_size)));
 }
 
 test "extern struct sizes match include/ptgpu.h" {
