@@ -213,7 +213,8 @@ enum {
     PT_FN_PHILOX = 8,      /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
     PT_FN_SCENE_HIT_FILTERED = 9, /* scene.zig:96 as the megakernel evaluates it (LDS filter + exact pass): in/out as PT_FN_SCENE_HIT */
     PT_FN_FILTER_BIT = 10  /* the LDS filter's verdict for one (ray, sphere) pair: in: o,d,c,r (10)  out: candidate bit,
-                              reference discriminant of sphere.zig:74 (2).  Invariant: discriminant >= 0 => bit == 1 */
+                              reference discriminant of sphere.zig:74, candidate bit of the shared-ordinate form of the
+                              test (3).  Invariant: discriminant >= 0 => both bits == 1 */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);

@@ -35,7 +35,7 @@ PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
 FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
     PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
     PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8),
-    PT_FN_FILTER_BIT: (10, 2)}
+    PT_FN_FILTER_BIT: (10, 3)}
 
 # pt_sphere: 36 bytes
 SPHERE_DTYPE = np.dtype(

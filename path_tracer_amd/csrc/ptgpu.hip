@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -86,7 +87,8 @@ struct KParams {
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
     uint32_t nspheres;
     uint32_t total_threads;
-    const float4 *filt; // (cx, cy, cz, threshold) padded to a multiple of kPad
+    const float4 *filt; // (cx, cz, threshold, cy) padded to a multiple of kPad
+    const float *ycy;   // per 32-sphere mask word (padded to whole tiles): the cy all its spheres share, or NaN
     const float4 *geom; // (cx, cy, cz, radius)
     const float4 *mat;  // (albedo r, g, b, param); dielectrics: (1/ri, schlick r0, 0, ri)
     const float *inv_radius; // 1/radius, correctly rounded (the value sphere.zig:88 computes per hit)
@@ -155,8 +157,24 @@ __device__ __forceinline__ float filter_value(const FilterRay &r, float cx, floa
     return fmaf(q, q, s);
 }
 
+// The same value for a sphere whose centre ordinate cy is shared by its whole mask word (32 consecutive
+// spheres): the cy terms are loop invariants of that word — Qy = cy*hy and Ey = cy*wy + E are formed once per
+// ray and word, and a test is 5 FMA-class instructions instead of 7.  (Scene 21: 484 of the 488 spheres rest on
+// the ground with cy = 0.2, scene.zig:62.)  Same terms, another association: the rounding budget of the
+// threshold (filter_threshold_of) bounds sums of |terms| and covers both.
+__device__ __forceinline__ float filter_value_y(const FilterRay &r, float Qy, float Ey, float cx, float cz) {
+    float q = fmaf(cx, r.hx, Qy);
+    q = fmaf(cz, r.hz, q);
+    float s = fmaf(cx, r.wx, Ey);
+    s = fmaf(cz, r.wz, s);
+    return fmaf(q, q, s);
+}
+#ifndef PT_YCLASS
+#define PT_YCLASS 1 // 0: every word takes the general 7-FMA test (A/B builds)
+#endif
+
 template <bool MULTI_TILE, class GeomOf>
-__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
+__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, const float *g_ycy, float *s_ycy_all, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
                                                       uint32_t tid, GeomOf geom_of, V3 o, V3 d, float a, float t_min, float t_max,
                                                       float &closest, int &hit, uint32_t &n_cands,
                                                       uint32_t &n_flush_iters, unsigned long long &t_flush) {
@@ -175,12 +193,14 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
             if (MULTI_TILE) {
                 __syncthreads();
                 for (uint32_t i = tid; i < tile_n; i += kBlock) s_filt_all[i] = g_filt[tile0 + i];
+                if (tid < (uint32_t)(kTile / 32)) s_ycy_all[tid] = g_ycy[(tile0 >> 5) + tid];
                 __syncthreads();
             }
           constexpr uint32_t MASK_TILE = (uint32_t)mask_tile(MULTI_TILE);
           for (uint32_t grp = 0; grp < tile_n; grp += MASK_TILE) { // scan MASK_TILE spheres, then the exact pass
             const uint32_t tile = tile0 + grp;                // first sphere of this group
             const float4 *s_filt = s_filt_all + grp;
+            const float *s_ycy = s_ycy_all + (grp >> 5);      // per mask word: the shared cy, or NaN = no shared ordinate
             const uint32_t tn = min(MASK_TILE, tile_n - grp); // multiple of kPad
             const uint32_t nw = (tn + 31u) >> 5;              // words of this group
             const uint32_t g_last = tn - ((nw - 1u) << 5);    // tests in the last word
@@ -197,25 +217,49 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, uint
 #pragma unroll
             for (int k = 0; k < kSub; ++k) fr[k] = s_filt[k];
             auto test_and_refill = [&](float4 &f, uint32_t next) {
-                const float F = filter_value(fray, f.x, f.y, f.z);
+                const float F = filter_value(fray, f.x, f.w, f.y); // records are (cx, cz, T, cy)
                 // candidate iff F >= T
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.w), "v"(F) : "vcc");
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.z), "v"(F) : "vcc");
                 f = s_filt[next];
+            };
+            float Qy = 0.f, Ey = 0.f;
+            auto test_and_refill_y = [&](float4 &f, uint32_t next, bool refill = true) {
+                const float F = filter_value_y(fray, Qy, Ey, f.x, f.y); // cy (f.w) is not read, but stays an operand so that
+                // the record is still fetched with ONE ds_read_b128: measured on MI355X (64 samples of the headline frame),
+                // general test 104.5 ms; this test with ds_read_b32 + ds_read_b64 96.0, ds_read_b96 113.0, ds_read_b128 92.2
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.z), "v"(F), "v"(f.w) : "vcc");
+                if (refill) f = s_filt[next];
+            };
+            // One full mask word (32 tests) starting at test j of the group; `J` = the same as a constant part for
+            // the unrolled callers.  The word's class is wave-uniform (one LDS broadcast read, one scalar branch).
+            auto word32 = [&](uint32_t j) {
+#if PT_YCLASS
+                const float cyw = s_ycy[j >> 5];
+                const uint32_t cyb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cyw));
+                if (cyb != 0x7fc00000u) {
+                    const float cyu = __uint_as_float(cyb);
+                    Qy = cyu * fray.hy;
+                    Ey = fmaf(cyu, fray.wy, fray.E);
+#pragma unroll
+#ifdef PT_EXPERIMENT_HALF_LDS // timing experiment (breaks parity): every other record is not fetched
+                    for (int k = 0; k < 32; ++k) test_and_refill_y(fr[k % kSub], j + (uint32_t)k + (uint32_t)kSub, (k & 1) == 0);
+#else
+                    for (int k = 0; k < 32; ++k) test_and_refill_y(fr[k % kSub], j + (uint32_t)k + (uint32_t)kSub);
+#endif
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j + (uint32_t)k + (uint32_t)kSub);
+                }
+                store_word(j >> 5, 32u);
             };
             uint32_t j0 = 0;
             for (; j0 + 32u * PT_WORDS_PER_ITER <= tn; j0 += 32u * PT_WORDS_PER_ITER) { // whole mask words per iteration: LDS offsets are immediates
 #pragma unroll
-                for (int w = 0; w < PT_WORDS_PER_ITER; ++w) {
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)(32 * w + k) + (uint32_t)kSub);
-                    store_word((j0 >> 5) + (uint32_t)w, 32u);
-                }
+                for (int w = 0; w < PT_WORDS_PER_ITER; ++w) word32(j0 + (uint32_t)(32 * w));
             }
-            for (; j0 + 32u <= tn; j0 += 32u) {
-#pragma unroll
-                for (int k = 0; k < 32; ++k) test_and_refill(fr[k % kSub], j0 + (uint32_t)k + (uint32_t)kSub);
-                store_word(j0 >> 5, 32u);
-            }
+            for (; j0 + 32u <= tn; j0 += 32u) word32(j0);
             if (j0 < tn) {                      // the last, partial word (a multiple of kPad tests)
                 for (; j0 < tn; j0 += kPad) {
 #pragma unroll
@@ -274,6 +318,7 @@ template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
     __shared__ float4 s_filt[kTile + kSub];                 // (cx, cy, cz, T) filter records of the current tile
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
+    __shared__ float s_ycy[kTile / 32];                     // per mask word of the tile: shared centre ordinate, or NaN
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
     __shared__ float s_radius[MULTI_TILE ? 1 : kTile];
@@ -288,6 +333,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     const uint32_t n_pad = (P.nspheres + kPad - 1) / kPad * kPad;
     if (!MULTI_TILE) {
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
+        if (tid < (uint32_t)(kTile / 32)) s_ycy[tid] = P.ycy[tid];
         for (uint32_t i = tid; i < P.nspheres; i += kBlock) {
             s_radius[i] = P.geom[i].w;
             s_inv_radius[i] = P.inv_radius[i];
@@ -299,8 +345,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     // exact sphere / material lookups (LDS for single-tile scenes)
     auto geom_of = [&](uint32_t j) -> float4 {
         if (MULTI_TILE) return P.geom[j];
-        const float4 f = s_filt[j];
-        return make_float4(f.x, f.y, f.z, s_radius[j]);
+        const float4 f = s_filt[j]; // (cx, cz, T, cy)
+        return make_float4(f.x, f.w, f.y, s_radius[j]);
     };
     auto inv_radius_of = [&](uint32_t j) -> float { return MULTI_TILE ? P.inv_radius[j] : s_inv_radius[j]; };
     auto mat_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.mat[j] : s_mat[j]; };
@@ -405,7 +451,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        scene_is_hit_filtered<MULTI_TILE>(P.filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
+        scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                           n_cands, n_flush_iters, t_flush);
         const bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
         if (tracing) n_rays++;
@@ -635,8 +681,10 @@ __global__ void pt_debug_filter_bit(const float *in, const float *thr, float *ou
     const V3 oc = vsub(o, v3(r[6], r[7], r[8]));
     const float half_b = vdot(oc, d);
     const float c = vlen2(oc) - r[9] * r[9];
-    out[(size_t)i * 2] = (thr[i] <= F) ? 1.0f : 0.0f; // v_cmp_le_f32 T, F
-    out[(size_t)i * 2 + 1] = half_b * half_b - a * c;
+    const float Fy = filter_value_y(fr, r[7] * fr.hy, fmaf(r[7], fr.wy, fr.E), r[6], r[8]); // as in a word that shares cy
+    out[(size_t)i * 3] = (thr[i] <= F) ? 1.0f : 0.0f; // v_cmp_le_f32 T, F
+    out[(size_t)i * 3 + 1] = half_b * half_b - a * c;
+    out[(size_t)i * 3 + 2] = (thr[i] <= Fy) ? 1.0f : 0.0f;
 }
 
 // cast_ray and scatter consume random draws: the debug variants take the draws from
@@ -663,15 +711,17 @@ __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t 
 // PT_FN_SCENE_HIT_FILTERED: the megakernel's own Scene.is_hit (LDS filter + exact pass) on caller
 // rays, one ray per thread, same output record as PT_FN_SCENE_HIT (the plain exact scan).
 template <bool MULTI_TILE>
-__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const float *in, float *out, uint32_t n, const float4 *g_filt,
+__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const float *in, float *out, uint32_t n, const float4 *g_filt, const float *g_ycy,
                                                                       const float4 *g_geom, uint32_t nspheres, float t_min, float t_max) {
     __shared__ float4 s_filt[kTile + kSub];
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock];
+    __shared__ float s_ycy[kTile / 32];
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
     const uint32_t n_pad = (nspheres + kPad - 1) / kPad * kPad;
     if (!MULTI_TILE) {
         for (uint32_t k = tid; k < n_pad; k += kBlock) s_filt[k] = g_filt[k];
+        if (tid < (uint32_t)(kTile / 32)) s_ycy[tid] = g_ycy[tid];
         __syncthreads();
     }
     const bool live = i < n;
@@ -683,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
     unsigned long long t_flush = 0;
     uint32_t n_cands = 0, n_flush_iters = 0;
     auto geom_of = [&](uint32_t j) -> float4 { return g_geom[j]; };
-    scene_is_hit_filtered<MULTI_TILE>(g_filt, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
+    scene_is_hit_filtered<MULTI_TILE>(g_filt, g_ycy, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
                                       n_flush_iters, t_flush);
     if (!live) return;
     float *w = out + (size_t)i * 8;
@@ -715,6 +765,7 @@ struct ptgpu_ctx {
     float4 *d_filt = nullptr, *d_geom = nullptr, *d_mat = nullptr;
     uint32_t *d_kind = nullptr;
     float *d_inv_radius = nullptr;
+    float *d_ycy = nullptr;
     bool have_camera = false;
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
@@ -818,7 +869,7 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
 extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PT_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
+    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -886,7 +937,7 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     std::vector<uint32_t> kind(n);
     for (uint32_t i = 0; i < n; ++i) {
         const pt_sphere &s = spheres[i];
-        filt[i] = make_float4(s.cx, s.cy, s.cz, filter_threshold(s));
+        filt[i] = make_float4(s.cx, s.cz, filter_threshold(s), s.cy);
         geom[i] = make_float4(s.cx, s.cy, s.cz, s.radius);
         // per-sphere values the reference recomputes at every hit, in the same f32 arithmetic (this file is
         // built with -ffp-contract=off; host float division is correctly rounded like the device's)
@@ -895,14 +946,26 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
                                            : make_float4(s.ar, s.ag, s.ab, s.param);
         kind[i] = s.kind;
     }
-    for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, 0.f, INFINITY); // never a candidate
+    for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, INFINITY, 0.f); // never a candidate
+    // Mask words (32 consecutive spheres) whose spheres all share one finite centre ordinate take the 5-FMA test
+    // (filter_value_y); the table is padded to whole LDS tiles, NaN = general test.  Pad records match any class.
+    const uint32_t n_words = (n_pad + (uint32_t)kTile - 1) / (uint32_t)kTile * (uint32_t)(kTile / 32);
+    std::vector<float> ycy(n_words, __builtin_nanf(""));
+    for (uint32_t w = 0; w * 32u < n; ++w) {
+        const uint32_t lo = w * 32u, hi = std::min(n, lo + 32u);
+        bool same = std::isfinite(spheres[lo].cy);
+        for (uint32_t i = lo + 1; i < hi && same; ++i) same = memcmp(&spheres[i].cy, &spheres[lo].cy, sizeof(float)) == 0;
+        if (same) ycy[w] = spheres[lo].cy;
+    }
+    for (float &v : ycy) if (v != v) { const uint32_t q = 0x7fc00000u; memcpy(&v, &q, 4); } // the kernel compares these bits
     // Build the new tables aside and swap them in only when every step succeeded: a failure leaves the
     // context with its previous scene intact (never half-updated).
-    void *fresh[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    const void *src[5] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data()};
-    const size_t bytes[5] = {n_pad * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(uint32_t), n * sizeof(float)};
+    void *fresh[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void *src[6] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data(), ycy.data()};
+    const size_t bytes[6] = {n_pad * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(uint32_t), n * sizeof(float),
+                             n_words * sizeof(float)};
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 5 && e == hipSuccess; ++i) {
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
         e = hipMalloc(&fresh[i], bytes[i]);
         if (e == hipSuccess) e = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
     }
@@ -911,9 +974,9 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
         ctx->last_hip = (int)e;
         return (e == hipErrorOutOfMemory) ? PT_ERR_OOM : PT_ERR_HIP;
     }
-    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius};
+    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy};
     ctx->d_filt = (float4 *)fresh[0]; ctx->d_geom = (float4 *)fresh[1]; ctx->d_mat = (float4 *)fresh[2];
-    ctx->d_kind = (uint32_t *)fresh[3]; ctx->d_inv_radius = (float *)fresh[4];
+    ctx->d_kind = (uint32_t *)fresh[3]; ctx->d_inv_radius = (float *)fresh[4]; ctx->d_ycy = (float *)fresh[5];
     ctx->nspheres = n;
     ctx->n_pad = n_pad;
     for (void *p : olds) if (p) (void)hipFree(p);
@@ -1062,7 +1125,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
-    P.filt = ctx->d_filt; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
+    P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
 
@@ -1217,7 +1280,7 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_REFLECT: in_stride = 6; out_stride = 3; break;
     case PT_FN_LERP: in_stride = 9; out_stride = 4; break;
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
-    case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 2; break;
+    case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 3; break;
     default: return PT_ERR_UNSUPPORTED;
     }
     if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
@@ -1243,10 +1306,10 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)
                 hipLaunchKernelGGL((pt_debug_scene_hit_filtered<true>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
-                                   (const float4 *)ctx->d_filt, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
+                                   (const float4 *)ctx->d_filt, (const float *)ctx->d_ycy, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
             else
                 hipLaunchKernelGGL((pt_debug_scene_hit_filtered<false>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
-                                   (const float4 *)ctx->d_filt, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
+                                   (const float4 *)ctx->d_filt, (const float *)ctx->d_ycy, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
         } else if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER)
             hipLaunchKernelGGL(pt_debug_eval_rng, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam);
         else

@@ -245,7 +245,7 @@ def test_filter_invariant_discriminant_nonneg_implies_candidate(gpu):
     for o_scale, c_scale in ((5.0, 12.0), (30.0, 30.0), (1000.0, 1000.0), (1000.0, 5.0), (0.0, 1000.0), (2000.0, 2000.0)):
         pairs = _pairs(rng, 200000, o_scale, c_scale)
         out = gpu.debug_eval(_lib.PT_FN_FILTER_BIT, pairs)
-        bit, disc = out[:, 0] == 1.0, out[:, 1]
+        bit, disc = (out[:, 0] == 1.0) & (out[:, 2] == 1.0), out[:, 1]   # general and shared-ordinate forms of the test
         # the device's discriminant is the reference's f32 arithmetic: cross-check against numpy float32
         o, d, c, r = pairs[:, 0:3], pairs[:, 3:6], pairs[:, 6:9], pairs[:, 9]
         oc = (o - c).astype(F)
@@ -255,6 +255,7 @@ def test_filter_invariant_discriminant_nonneg_implies_candidate(gpu):
         np.testing.assert_array_equal(disc, (half_b * half_b - a * cc).astype(F))
         bad = (disc >= 0) & ~bit
         assert not bad.any(), (o_scale, c_scale, pairs[bad][:3], disc[bad][:3])
+        assert ((out[:, 0] == 1.0) == (out[:, 2] == 1.0)).mean() > 0.999          # the two forms agree except at the margin
         total += len(pairs); nonneg += int((disc >= 0).sum()); cand += int(bit.sum())
     assert total >= 1_000_000 and nonneg > 100_000          # the invariant was exercised, not vacuous
     assert cand < 0.9 * total                               # and the filter does reject
