@@ -34,10 +34,11 @@ def algorithmic_flops(paths, rays, nspheres):
     return rays * nspheres * 18.0 + rays * 60.0 + paths * 40.0
 
 
-def executed_flops(paths, rays, nspheres):
-    """What the shipped kernel executes per ray-sphere test: 7 FMA + 1 compare (15 FLOP) on every lane; the exact
-    test runs on the filter's survivors only (inside the per-ray term)."""
-    return rays * nspheres * 15.0 + rays * 60.0 + paths * 40.0
+def executed_flops(paths, rays, nspheres, shared_tests):
+    """What the shipped kernel executes per ray-sphere test: 7 FMA + 1 compare (15 FLOP) on every lane, or 5 FMA + 1
+    compare (11 FLOP) for the `shared_tests` spheres in shared-ordinate mask words; the exact test runs on the
+    filter's survivors only (inside the per-ray term)."""
+    return rays * ((nspheres - shared_tests) * 15.0 + shared_tests * 11.0) + rays * 60.0 + paths * 40.0
 
 
 def cpu_baseline(width, depth, seed):
@@ -193,11 +194,12 @@ def main():
                          "kernel": "pt_megakernel", "kernel_ms": k_ms,
                          "flops_per_launch": flops_per_launch,
                          "basis": "algorithmic",
-                         "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph) / (k_ms * 1e-3) / PEAK_FP32_VALU,
+                         "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph, gpu.scene_info()["shared_ordinate_tests"])
+                                          / (k_ms * 1e-3) / PEAK_FP32_VALU,
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d). `achieved`/`frac` price the "
                                  "ALGORITHMIC work of the reference's scan: 18 FLOP/ray-sphere test + 60/ray + 40/path over the "
                                  "device-counted rays of rank 0's launch — an algorithmic-work rate, not hardware utilisation. "
-                                 "`executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP); "
+                                 "`executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP; 5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words); "
                                  "issue-slot utilisation from the SQ counters is in profiles/"},
         }
         if args.rehearse_gloo:

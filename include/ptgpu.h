@@ -263,6 +263,9 @@ enum { PT_LIMIT_PARTIAL_BYTES = 0 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
 
 /* Diagnostics. */
+/* The uploaded scene: its sphere count, and how many of them sit in mask words (32 consecutive spheres) that share
+ * one centre ordinate and therefore take the filter's 5-FMA test instead of the 7-FMA one. */
+int ptgpu_scene_info(const ptgpu_ctx *ctx, uint32_t *nspheres, uint32_t *shared_ordinate_tests);
 int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
 const char *ptgpu_strerror(int status);
 int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */

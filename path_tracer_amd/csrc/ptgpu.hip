@@ -766,6 +766,7 @@ struct ptgpu_ctx {
     uint32_t *d_kind = nullptr;
     float *d_inv_radius = nullptr;
     float *d_ycy = nullptr;
+    uint32_t shared_tests = 0; // spheres in shared-ordinate mask words (5-FMA filter test)
     bool have_camera = false;
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
@@ -895,6 +896,13 @@ extern "C" int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out) {
     return PT_OK;
 }
 
+extern "C" int ptgpu_scene_info(const ptgpu_ctx *ctx, uint32_t *nspheres, uint32_t *shared_ordinate_tests) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (nspheres) *nspheres = ctx->nspheres;
+    if (shared_ordinate_tests) *shared_ordinate_tests = ctx->shared_tests;
+    return PT_OK;
+}
+
 extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
     if (!ctx) return PT_ERR_BAD_ARG;
     switch (which) {
@@ -979,6 +987,8 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     ctx->d_kind = (uint32_t *)fresh[3]; ctx->d_inv_radius = (float *)fresh[4]; ctx->d_ycy = (float *)fresh[5];
     ctx->nspheres = n;
     ctx->n_pad = n_pad;
+    ctx->shared_tests = 0;
+    for (uint32_t w = 0; w * 32u < n; ++w) if (ycy[w] == ycy[w]) ctx->shared_tests += 32u;
     for (void *p : olds) if (p) (void)hipFree(p);
     return PT_OK;
 }

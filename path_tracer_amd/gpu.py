@@ -114,6 +114,11 @@ class GpuContext:
         check(self._L.ptgpu_get_stats(self._h, C.byref(st)), "ptgpu_get_stats")
         return st
 
+    def scene_info(self):
+        n, shared = C.c_uint32(), C.c_uint32()
+        check(self._L.ptgpu_scene_info(self._h, C.byref(n), C.byref(shared)), "ptgpu_scene_info")
+        return {"nspheres": n.value, "shared_ordinate_tests": shared.value}
+
     def device_info(self):
         cu, khz = C.c_int(), C.c_int()
         arch = C.create_string_buffer(64)
