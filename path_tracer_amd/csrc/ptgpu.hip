@@ -8,7 +8,8 @@
 //     work item from an atomic queue; a wave reserves 64 items per atomic and deals them
 //     out by ballot/popcount ranks) — replaces the thread split of multithreading.zig;
 //   * Scene.is_hit (scene.zig:96-110) = a linear scan over a filter table
-//     (cx,cy,cz,threshold) staged into LDS in tiles: 7 FMAs + 1 compare per sphere
+//     (cx,cz,threshold,cy) staged into LDS in tiles: 7 FMAs + 1 compare per sphere (5 + 1 when the 32 spheres
+//     of a mask word share their centre ordinate)
 //     decide conservatively whether the reference's discriminant can be >= 0 and one
 //     v_addc shifts the verdict into a per-lane bit word (no branch in the scan); the
 //     few survivors are evaluated afterwards with the reference's exact arithmetic
@@ -223,15 +224,14 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
                 f = s_filt[next];
             };
             float Qy = 0.f, Ey = 0.f;
-            auto test_and_refill_y = [&](float4 &f, uint32_t next, bool refill = true) {
+            auto test_and_refill_y = [&](float4 &f, uint32_t next) {
                 const float F = filter_value_y(fray, Qy, Ey, f.x, f.y); // cy (f.w) is not read, but stays an operand so that
                 // the record is still fetched with ONE ds_read_b128: measured on MI355X (64 samples of the headline frame),
                 // general test 104.5 ms; this test with ds_read_b32 + ds_read_b64 96.0, ds_read_b96 113.0, ds_read_b128 92.2
                 asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(f.z), "v"(F), "v"(f.w) : "vcc");
-                if (refill) f = s_filt[next];
+                f = s_filt[next];
             };
-            // One full mask word (32 tests) starting at test j of the group; `J` = the same as a constant part for
-            // the unrolled callers.  The word's class is wave-uniform (one LDS broadcast read, one scalar branch).
+            // One full mask word (32 tests) starting at test j of the group.  The word's class is wave-uniform (one LDS broadcast read, one scalar branch).
             auto word32 = [&](uint32_t j) {
 #if PT_YCLASS
                 const float cyw = s_ycy[j >> 5];
@@ -241,11 +241,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
                     Qy = cyu * fray.hy;
                     Ey = fmaf(cyu, fray.wy, fray.E);
 #pragma unroll
-#ifdef PT_EXPERIMENT_HALF_LDS // timing experiment (breaks parity): every other record is not fetched
-                    for (int k = 0; k < 32; ++k) test_and_refill_y(fr[k % kSub], j + (uint32_t)k + (uint32_t)kSub, (k & 1) == 0);
-#else
                     for (int k = 0; k < 32; ++k) test_and_refill_y(fr[k % kSub], j + (uint32_t)k + (uint32_t)kSub);
-#endif
                 } else
 #endif
                 {
@@ -316,7 +312,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 // several CUs share, long before LDS.
 template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
-    __shared__ float4 s_filt[kTile + kSub];                 // (cx, cy, cz, T) filter records of the current tile
+    __shared__ float4 s_filt[kTile + kSub];                 // (cx, cz, T, cy) filter records of the current tile
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
     __shared__ float s_ycy[kTile / 32];                     // per mask word of the tile: shared centre ordinate, or NaN
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
@@ -955,12 +951,12 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
         kind[i] = s.kind;
     }
     for (uint32_t i = n; i < n_pad; ++i) filt[i] = make_float4(0.f, 0.f, INFINITY, 0.f); // never a candidate
-    // Mask words (32 consecutive spheres) whose spheres all share one finite centre ordinate take the 5-FMA test
+    // Full mask words (32 consecutive spheres) whose spheres all share one finite centre ordinate take the 5-FMA test
     // (filter_value_y); the table is padded to whole LDS tiles, NaN = general test.  Pad records match any class.
     const uint32_t n_words = (n_pad + (uint32_t)kTile - 1) / (uint32_t)kTile * (uint32_t)(kTile / 32);
     std::vector<float> ycy(n_words, __builtin_nanf(""));
-    for (uint32_t w = 0; w * 32u < n; ++w) {
-        const uint32_t lo = w * 32u, hi = std::min(n, lo + 32u);
+    for (uint32_t w = 0; (w + 1) * 32u <= n; ++w) { // full words only: the last, partial word always takes the general test
+        const uint32_t lo = w * 32u, hi = lo + 32u;
         bool same = std::isfinite(spheres[lo].cy);
         for (uint32_t i = lo + 1; i < hi && same; ++i) same = memcmp(&spheres[i].cy, &spheres[lo].cy, sizeof(float)) == 0;
         if (same) ycy[w] = spheres[lo].cy;

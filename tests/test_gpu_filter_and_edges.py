@@ -259,3 +259,42 @@ def test_filter_invariant_discriminant_nonneg_implies_candidate(gpu):
         total += len(pairs); nonneg += int((disc >= 0).sum()); cand += int(bit.sum())
     assert total >= 1_000_000 and nonneg > 100_000          # the invariant was exercised, not vacuous
     assert cand < 0.9 * total                               # and the filter does reject
+
+
+# ---- shared-ordinate mask words ----------------------------------------------------------------------------
+@pytest.mark.parametrize("nspheres,pattern", [(700, "all"), (1500, "runs"), (96, "all"), (100, "alternate"), (40, "negzero")])
+def test_shared_ordinate_words_against_oracle(orc, gpu, nspheres, pattern):
+    """Mask words (32 consecutive spheres) whose spheres share one centre ordinate take the filter's short test.
+    Scenes built to mix both kinds of word in one tile and across tiles — all words shared; runs of shared and
+    general words; a shared word followed by a partial one; no word shared because two values alternate; +0.0 vs
+    -0.0 (different bits: not shared) — must still equal the oracle bit for bit, and the filtered Scene.is_hit the
+    plain exact scan."""
+    from path_tracer_amd import _lib, host
+    sp = host.Scene().sceneSynthetic(nspheres, 9).spheres.copy()
+    idx = np.arange(nspheres)
+    if pattern == "all":
+        sp["cy"] = 0.25
+    elif pattern == "runs":
+        run = (idx // 32) % 3 != 1                 # words 0, 2, 3, 5, 6, ... shared, words 1, 4, 7, ... general
+        sp["cy"][run] = (0.2 + 0.01 * ((idx // 32) % 5))[run].astype(F)
+    elif pattern == "alternate":
+        sp["cy"] = np.where(idx % 2 == 0, 0.25, 0.3).astype(F)
+    elif pattern == "negzero":
+        sp["cy"] = np.where(idx % 2 == 0, 0.0, -0.0).astype(F)
+    sp["cy"][0] = -1000.0                          # the ground sphere keeps its own centre: word 0 is general
+    gpu.set_scene(sp)
+    info = gpu.scene_info()
+    expect = {"all": (nspheres // 32 - 1) * 32, "alternate": 0, "negzero": 0}.get(pattern)
+    if expect is not None:
+        assert info["shared_ordinate_tests"] == expect
+    else:
+        assert 0 < info["shared_ordinate_tests"] < nspheres
+    cam = host.Camera.preset(21)
+    gpu.set_camera(cam.pod)
+    img = host.Image(48)
+    rt = host.RayTracerConfig(subpixels=2, rays_per_subsample=2, rebounds=12)
+    _cmp_render(orc, gpu, sp, cam.pod, host.make_pt_config(img, rt, seed=4))
+    rng = np.random.default_rng(nspheres)
+    rays = np.concatenate([_grazing_rays(rng, sp, 20000, 15.0),
+                           np.concatenate([rng.normal(0, 20, (10000, 3)).astype(F), _unit(rng.normal(0, 1, (10000, 3)))], axis=1)])
+    _compare(gpu, rays)
