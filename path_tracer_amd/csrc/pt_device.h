@@ -118,7 +118,9 @@ struct ArrayRng { // per-function parity vectors: draws supplied by the caller
 
 // The reference's rejection loops are unbounded; both the oracle and this code stop
 // after PT_MAX_TRIES and keep the last draw, so every wave reaches the loop's exit.
+#ifndef PT_MAX_TRIES // overridden only by timing experiments (tools/build_variant.sh)
 #define PT_MAX_TRIES 256
+#endif
 
 // material.zig:27-34 — components in [0,1): positive octant of the unit ball
 template <class R>

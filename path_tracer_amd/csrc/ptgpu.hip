@@ -70,7 +70,7 @@ static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0,
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 16 };
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
 struct KParams {
     Cam cam;
@@ -119,9 +119,11 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #ifdef PT_PHASE_TIMING
 #define PT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PT_ACC(idx, a, b) t_phase[idx] += (b) - (a)
+#define PT_SUB_ACC(idx, a, b) t_sub[idx] += (b) - (a)
 #else
 #define PT_STAMP(var)
 #define PT_ACC(idx, a, b)
+#define PT_SUB_ACC(idx, a, b)
 #endif
 
 // Scene.is_hit (scene.zig:96-110) for the 64 rays of a wave: conservative filter scan over the LDS
@@ -269,6 +271,9 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
             PT_STAMP(tF0);
             {
                 uint32_t mw = 0, wcur = 0, gcur = 32;
+#ifdef PT_EXPERIMENT_FLUSH_MAX
+                uint32_t n_flush_iters_here = 0;
+#endif
                 for (;;) {
                     if (mw == 0u && S != 0u) {
                         const uint32_t b = 31u - (uint32_t)__clz((int)S);
@@ -279,6 +284,9 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
                     }
                     const bool has = mw != 0u;
                     if (__ballot(has) == 0ull) break;
+#ifdef PT_EXPERIMENT_FLUSH_MAX // timing experiment (breaks parity): at most this many exact-pass iterations per group
+                    if (n_flush_iters_here++ >= PT_EXPERIMENT_FLUSH_MAX) break;
+#endif
                     n_flush_iters++;
                     if (has) {
                         const uint32_t b = 31u - (uint32_t)__clz((int)mw);
@@ -363,6 +371,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
     unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
+    unsigned long long t_sub[4] = {0, 0, 0, 0};      // within C: hit point, scatter, miss (lerp + unwinding); within A: path start
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
@@ -426,6 +435,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             if (__ballot(alive) == 0ull) break;
         }
         // sample == s_end here only for a lane whose new item was empty (cut tile): it must not start a path
+        PT_STAMP(tP0);
         if (alive && need_path && sample != s_end) {
             // renderers/ppm_image.zig:50-51,61-63
             rng.start_path(pixel, sample);
@@ -439,6 +449,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             bounce = 0;
             need_path = false;
         }
+        PT_STAMP(tP1);
+        PT_SUB_ACC(3, tP0, tP1);
 
         // ---- phase B: Scene.is_hit (scene.zig:96-110) ---------------------------
         PT_STAMP(tB0);
@@ -480,8 +492,12 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     const float4 m = mat_of((uint32_t)hit);
                     const uint32_t kind = kind_of((uint32_t)hit);
                     V3 p, n;
+                    PT_STAMP(tH0);
                     sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
+                    PT_STAMP(tH1);
                     const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                    PT_STAMP(tH2);
+                    PT_SUB_ACC(0, tH0, tH1); PT_SUB_ACC(1, tH1, tH2);
 #ifndef PT_EXPERIMENT_NO_STACK // tools/build_variant.sh timing experiment (breaks parity)
                     P.stack[(size_t)bounce * P.total_threads + gtid] = (uint32_t)hit;
 #endif
@@ -489,6 +505,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     o = p; d = nd;
                 }
             } else {
+                PT_STAMP(tM0);
                 ok = lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color); // illumination.zig:88
                 // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
                 for (uint32_t b = bounce; b > 0; --b) {
@@ -504,6 +521,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                         color = vemul(color, v3(1.0f, 1.0f, 1.0f)); // material.zig:135
                     }
                 }
+                PT_STAMP(tM1);
+                PT_SUB_ACC(2, tM0, tM1);
                 done = true;
             }
             if (done) {
@@ -523,6 +542,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         atomicAdd(&P.counters[13], __builtin_amdgcn_s_memrealtime() - r_begin);
         t_phase[2] = t_flush;
         for (int i = 0; i < 5; ++i) atomicAdd(&P.counters[8 + i], t_phase[i]);
+        for (int i = 0; i < 4; ++i) atomicAdd(&P.counters[16 + i], t_sub[i]);
     }
 #endif
     // ---- statistics ---------------------------------------------------------------
@@ -1171,6 +1191,8 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         fprintf(stderr, "[phase timing] shader clock %.0f MHz (s_memtime / s_memrealtime)\n", tot / (double)h[13] * 100.0);
         fprintf(stderr, "[phase timing] share of wave cycles: refill %.3f  scan %.3f  (of which flush %.3f)  shade %.3f\n",
                 h[8] / tot, h[9] / tot, h[10] / tot, h[11] / tot);
+        fprintf(stderr, "[phase timing]   within shade: hit point %.3f  scatter %.3f  miss (lerp + unwinding) %.3f;  within refill: path start %.3f\n",
+                h[16] / tot, h[17] / tot, h[18] / tot, h[19] / tot);
     }
 #endif
     ctx->stats.wave_steps = h[CNT_WAVE_STEPS];
