@@ -144,12 +144,13 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, paths, rays = [], 0, 0
+    kernel_ms, paths, rays, wave_steps = [], 0, 0, 0
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st.kernel_ms)   # HIP events around the megakernel, on the stream it ran on
         paths += st.paths
         rays += st.rays
+        wave_steps += st.wave_steps
     fence()
     dt = time.perf_counter() - t0
 
@@ -193,6 +194,8 @@ def main():
                          "frac": achieved / PEAK_FP32_VALU, "traffic": None,
                          "kernel": "pt_megakernel", "kernel_ms": k_ms,
                          "flops_per_launch": flops_per_launch,
+                         "rays_per_launch": rays / args.steps, "wave_steps_per_launch": wave_steps / args.steps,
+                         "spheres": nsph, "shared_ordinate_tests": gpu.scene_info()["shared_ordinate_tests"],
                          "basis": "algorithmic",
                          "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph, gpu.scene_info()["shared_ordinate_tests"])
                                           / (k_ms * 1e-3) / PEAK_FP32_VALU,

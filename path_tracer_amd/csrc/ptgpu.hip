@@ -89,6 +89,7 @@ struct KParams {
     uint32_t nspheres;
     uint32_t total_threads;
     const float4 *filt; // (cx, cz, threshold, cy) padded to a multiple of kPad
+    uint32_t has_shared; // any shared-ordinate word in the scene
     const float *ycy;   // per 32-sphere mask word (padded to whole tiles): the cy all its spheres share, or NaN
     const float4 *geom; // (cx, cy, cz, radius)
     const float4 *mat;  // (albedo r, g, b, param); dielectrics: (1/ri, schlick r0, 0, ri)
@@ -177,7 +178,7 @@ __device__ __forceinline__ float filter_value_y(const FilterRay &r, float Qy, fl
 #endif
 
 template <bool MULTI_TILE, class GeomOf>
-__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, const float *g_ycy, float *s_ycy_all, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
+__device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, const float *g_ycy, bool has_shared, float *s_ycy_all, uint32_t n_pad, float4 *s_filt_all, uint32_t *s_mask,
                                                       uint32_t tid, GeomOf geom_of, V3 o, V3 d, float a, float t_min, float t_max,
                                                       float &closest, int &hit, uint32_t &n_cands,
                                                       uint32_t &n_flush_iters, unsigned long long &t_flush) {
@@ -196,7 +197,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
             if (MULTI_TILE) {
                 __syncthreads();
                 for (uint32_t i = tid; i < tile_n; i += kBlock) s_filt_all[i] = g_filt[tile0 + i];
-                if (tid < (uint32_t)(kTile / 32)) s_ycy_all[tid] = g_ycy[(tile0 >> 5) + tid];
+                if (has_shared && tid < (uint32_t)(kTile / 32)) s_ycy_all[tid] = g_ycy[(tile0 >> 5) + tid];
                 __syncthreads();
             }
           constexpr uint32_t MASK_TILE = (uint32_t)mask_tile(MULTI_TILE);
@@ -236,8 +237,8 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
             // One full mask word (32 tests) starting at test j of the group.  The word's class is wave-uniform (one LDS broadcast read, one scalar branch).
             auto word32 = [&](uint32_t j) {
 #if PT_YCLASS
-                const float cyw = s_ycy[j >> 5];
-                const uint32_t cyb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cyw));
+                // has_shared (kernel argument): scenes without any shared-ordinate word skip the class look-up altogether
+                const uint32_t cyb = has_shared ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s_ycy[j >> 5])) : 0x7fc00000u;
                 if (cyb != 0x7fc00000u) {
                     const float cyu = __uint_as_float(cyb);
                     Qy = cyu * fray.hy;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
+        scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                           n_cands, n_flush_iters, t_flush);
         const bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
         if (tracing) n_rays++;
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
     unsigned long long t_flush = 0;
     uint32_t n_cands = 0, n_flush_iters = 0;
     auto geom_of = [&](uint32_t j) -> float4 { return g_geom[j]; };
-    scene_is_hit_filtered<MULTI_TILE>(g_filt, g_ycy, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
+    scene_is_hit_filtered<MULTI_TILE>(g_filt, g_ycy, true, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, t_min, t_max, closest, hit, n_cands,
                                       n_flush_iters, t_flush);
     if (!live) return;
     float *w = out + (size_t)i * 8;
@@ -1151,7 +1152,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
-    P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
+    P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
 

@@ -35,6 +35,16 @@ derived = {
     "waitcnt/barrier share (SQ_WAIT_ANY / SQ_WAVE_CYCLES)": vals["SQ_WAIT_ANY"] / wc,
     "VALU wave-instruction issue interval per SIMD, ns (kernel time * 1024 SIMDs / SQ_INSTS_VALU)": kms * 1e6 * 1024 / vals["SQ_INSTS_VALU"],
 }
+rl = bench["roofline"]
+if "wave_steps_per_launch" in rl:
+    steps = rl["wave_steps_per_launch"]
+    per_step = vals["SQ_INSTS_VALU"] / steps
+    scan = rl["shared_ordinate_tests"] * 7 + (rl["spheres"] - rl["shared_ordinate_tests"]) * 9
+    derived["VALU wave-instructions per ray step (SQ_INSTS_VALU / wave steps of the launch)"] = per_step
+    derived["of which the filter scan (7 per test in shared-ordinate words, 9 otherwise)"] = scan
+    derived["VALU wave-instructions per ray step outside the scan"] = per_step - scan
+    derived["SALU wave-instructions per ray step"] = vals["SQ_INSTS_SALU"] / steps
+    derived["LDS wave-instructions per ray step"] = vals["SQ_INSTS_LDS"] / steps
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     # rocprofv3 derived metrics, in KB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B
     # (double it for wide coalesced reads); other widths are uncalibrated, so both figures are orders of magnitude
