@@ -126,7 +126,10 @@ struct ArrayRng { // per-function parity vectors: draws supplied by the caller
 template <class R>
 __device__ __forceinline__ V3 random_vector_in_unit_sphere(R &r) {
     V3 p = v3(0.f, 0.f, 0.f);
-    for (int tries = 0; tries < PT_MAX_TRIES; ++tries) {
+#ifndef PT_MAX_TRIES_SPHERE
+#define PT_MAX_TRIES_SPHERE PT_MAX_TRIES
+#endif
+    for (int tries = 0; tries < PT_MAX_TRIES_SPHERE; ++tries) {
         float x, y, z;
         r.next3(x, y, z);
         p = v3(x, y, z);
