@@ -128,9 +128,11 @@ typedef struct pt_stats {
     uint64_t not_unit;     /* lerp() directions failing illumination.zig:29          */
     uint64_t wave_steps;   /* ray steps executed by waves (rays / (64*wave_steps) = lane utilisation) */
     uint64_t flush_iters;  /* wave iterations of the exact-test loop                 */
-    double kernel_ms;      /* HIP-event time of the path-tracing kernel (of all segments, incl. their chunk sums, when segments > 1) */
+    double kernel_ms;      /* HIP-event time of the path-tracing kernels: primary pass + megakernel (of all segments, incl. their chunk sums, when segments > 1) */
     double total_ms;       /* kernel + chunk sums                                    */
-    uint64_t segments;     /* megakernel launches the render took (PT_LIMIT_PARTIAL_BYTES) */
+    uint64_t segments;     /* megakernel launches the render took (PT_LIMIT_PARTIAL_BYTES, PT_LIMIT_PRIMARY_BYTES) */
+    uint64_t primary_rays; /* of `rays`: camera rays whose closest hit came from their pixel's candidate list (primary pass), not from the scan */
+    double primary_ms;     /* of kernel_ms: the primary pass (candidate lists + camera rays + first radiance step); 0 when segments > 1 */
 } pt_stats;
 
 typedef struct ptgpu_ctx ptgpu_ctx;
@@ -258,8 +260,17 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
 /* Limits.  PT_LIMIT_PARTIAL_BYTES (default 2 GiB): upper bound of the device buffer that holds the
  * chunk partial sums (chunks x pixels x 12 B).  A render that needs more is traced in segments of
  * pixels, one kernel launch each, through the same buffer; the result is bit-identical (a pixel's
- * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took. */
-enum { PT_LIMIT_PARTIAL_BYTES = 0 };
+ * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took.
+ *
+ * PT_LIMIT_PRIMARY_BYTES (default 24 GiB; 0 switches the primary pass off): upper bound of the device
+ * buffer of the primary pass: one 32-byte record per path of a launch plus 64 B of candidate list per
+ * pixel.  The primary pass traces every camera ray against the few spheres its pixel's rays can reach
+ * (a conservative per-pixel list built per launch) and shades the first hit; the megakernel continues the
+ * paths from the records, so its scan over all spheres only serves scattered rays.  Same closest hits,
+ * same draws, same sums: results do not depend on this limit, only segments and speed do.  The buffer is
+ * allocated at the size a render needs, not at the limit.  ptgpu_render_sum_device_noalloc never runs the
+ * primary pass (its records would not fit the static scratch). */
+enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
 
 /* Diagnostics. */

@@ -228,6 +228,18 @@ def render_sum(spheres, cam, cfg, nthreads=1):
     return rc, out, st
 
 
+def render_sum_zig(spheres, cam, cfg, rng):
+    """The reference's own sampler: main.zig:166-177's single-thread render() drawing from the sequential std.rand
+    stream that built the scene (`rng`: the state setup_scene returned; advanced in place) and material.zig:15's
+    module-level DefaultPrng.init(0) for the scatters."""
+    out = np.zeros((cfg.height, cfg.width, 3), dtype=np.float32)
+    st = Stats()
+    sp = np.ascontiguousarray(spheres)
+    rc = lib().orc_render_sum_zig(sp.ctypes.data, len(sp), C.byref(cam), C.byref(cfg), C.byref(rng), out.ctypes.data,
+                                  C.byref(st))
+    return rc, out, st
+
+
 def resolve_mean(cfg, rgb_sum):
     out = np.zeros_like(rgb_sum)
     lib().orc_resolve_mean(C.byref(cfg), rgb_sum.ctypes.data, out.ctypes.data)

@@ -25,6 +25,7 @@ PT_ERR_SCRATCH_LIMIT = -10
 PT_ERR_RCCL = -11
 
 PT_LIMIT_PARTIAL_BYTES = 0
+PT_LIMIT_PRIMARY_BYTES = 1
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
@@ -66,7 +67,8 @@ class pt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
-                ("total_ms", C.c_double), ("segments", C.c_uint64)]
+                ("total_ms", C.c_double), ("segments", C.c_uint64), ("primary_rays", C.c_uint64),
+                ("primary_ms", C.c_double)]
 
 
 assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104

@@ -68,9 +68,13 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 constexpr int kSub = PT_SUB;         // filter records held in registers ahead of their tests (software pipeline depth)
 static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
+// primary pass: candidate-list capacity per pixel and the record tags (bits 31:30 of rec_a.w)
+constexpr uint32_t kListCap = 16;
+constexpr uint32_t kListEnd = 0xffffffffu, kListOverflow = 0xfffffffeu;
+constexpr uint32_t kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 2u, kTagState1 = 3u;
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
 struct KParams {
     Cam cam;
@@ -96,6 +100,10 @@ struct KParams {
     const float *inv_radius; // 1/radius, correctly rounded (the value sphere.zig:88 computes per hit)
     const uint32_t *kind;
     float *part;        // direct ? frame[W*H][3] : [nchunks][npix][3] partial sums
+    // primary pass (pt_primary): one record per path of the launch, index item * chunk + (sample - item's first sample)
+    uint32_t primary;       // 1: the records exist; the megakernel starts its paths from them instead of casting camera rays
+    float4 *rec_a, *rec_b;  // (colour | origin, tag<<30 | first hit id), (direction, draws taken)
+    const uint32_t *lists;  // [npix][kListCap]: candidate spheres of each pixel slot's camera rays (pt_primary_lists)
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
 };
@@ -319,7 +327,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 // through the scalar cache instead (s_load_dwordx16 into SGPR operands: no VGPRs, no LDS reads)
 // was measured 15 % slower on MI355X — 16 B per wave per test saturates the scalar cache, which
 // several CUs share, long before LDS.
-template <bool DET, bool MULTI_TILE>
+template <bool DET, bool MULTI_TILE, bool PRIMARY>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
     __shared__ float4 s_filt[kTile + kSub];                 // (cx, cz, T, cy) filter records of the current tile
     __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     bool alive = true;      // lane still has (or can get) work
     bool need_path = true;  // lane needs a new camera sample
     uint32_t pixel = 0, sample = 0, s_end = 0, out_slot = 0;
+    uint32_t rec_base = 0;  // primary pass: record of (item, sample) = rec_base + sample
     bool has_item = false;
     V3 accum = v3(0.f, 0.f, 0.f);
     V3 o = v3(0.f, 0.f, 0.f), d = v3(kNaN, kNaN, kNaN); // parked (see phase A) until the first path starts
@@ -382,6 +391,10 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     for (;;) {
         // ---- phase A: refill lanes whose path has ended -------------------------
         PT_STAMP(tA0);
+        // With primary-pass records a lane can use up its item while starting a path (every remaining sample
+        // ended in the primary pass): such lanes get one more round — a new item and its records — before the
+        // wave goes into the scan.
+        for (int round = 0;; ++round) {
         if (alive && need_path && sample == s_end) {
             if (has_item) {
                 float *dst = P.part + 3ull * out_slot;
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                         const uint32_t po = item - k * P.npix;
                         pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
                         sample = P.s0 + k * P.chunk;
+                        if (PRIMARY) rec_base = item * P.chunk - sample;
                         s_end = min(sample + P.chunk, P.s1);
                         out_slot = P.direct ? pixel : item; // frame[pixel] or part[k][po]
                         accum = v3(0.f, 0.f, 0.f);
@@ -430,14 +444,37 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                 }
             }
         }
-        if (MULTI_TILE) {
-            if (!__syncthreads_or(alive ? 1 : 0)) break;
-        } else {
-            if (__ballot(alive) == 0ull) break;
-        }
         // sample == s_end here only for a lane whose new item was empty (cut tile): it must not start a path
         PT_STAMP(tP0);
-        if (alive && need_path && sample != s_end) {
+        if (PRIMARY) {
+            // The primary pass has traced every camera ray of this launch against its pixel's candidate list
+            // and shaded the first hit (pt_primary).  A record is the path's colour (it ended there: added
+            // here, in sample order), or the ray after the first bounce, or — pixels without a list — the
+            // camera ray itself.
+            if (alive && need_path && sample != s_end) {
+                for (;;) {
+                    const uint32_t r = rec_base + sample;
+                    const float4 ra = P.rec_a[r];
+                    const uint32_t meta = __float_as_uint(ra.w);
+                    const uint32_t tag = meta >> 30;
+                    if (tag >= kTagState0) {
+                        const float4 rb = P.rec_b[r];
+                        o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
+                        rng.resume(pixel, sample, __float_as_uint(rb.w));
+                        bounce = tag - kTagState0; // 0: camera ray, 1: after the first bounce
+                        if (bounce) P.stack[gtid] = meta & 0x3fffffffu; // stack[0][gtid]: the first hit's id
+                        need_path = false;
+                        break;
+                    }
+                    if (tag == kTagFinal) accum = vadd(accum, v3(ra.x, ra.y, ra.z)); // renderers/ppm_image.zig:67
+                    sample++;                    // kTagSkip: DirectionIsNotUnitVector, counted by the primary pass
+                    if (sample == s_end) {       // item finished without a ray to trace: ask for the next one, or park
+                        o = v3(0.f, 0.f, 0.f); d = v3(kNaN, kNaN, kNaN);
+                        break;
+                    }
+                }
+            }
+        } else if (alive && need_path && sample != s_end) {
             // renderers/ppm_image.zig:50-51,61-63
             rng.start_path(pixel, sample);
             const uint32_t i_col = pixel % P.width;
@@ -452,6 +489,14 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         }
         PT_STAMP(tP1);
         PT_SUB_ACC(3, tP0, tP1);
+        if (!PRIMARY || round == 1) break;
+        if (__ballot(alive && need_path) == 0ull) break;
+        } // rounds
+        if (MULTI_TILE) {
+            if (!__syncthreads_or(alive ? 1 : 0)) break;
+        } else {
+            if (__ballot(alive) == 0ull) break;
+        }
 
         // ---- phase B: Scene.is_hit (scene.zig:96-110) ---------------------------
         PT_STAMP(tB0);
@@ -556,6 +601,187 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         if (w_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], w_not_unit);
         atomicAdd(&P.counters[CNT_WAVE_STEPS], (unsigned long long)n_wave_steps);
         atomicAdd(&P.counters[CNT_FLUSH_ITERS], (unsigned long long)n_flush_iters);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the primary pass
+// ---------------------------------------------------------------------------
+// Camera rays are the one coherent ray population of the path: every ray of a pixel leaves the lens disk
+// and crosses that pixel's footprint on the focal plane.  pt_primary_lists finds, per pixel, the spheres ANY
+// such ray can hit (a conservative set, in ascending index); pt_primary then gives each camera ray the
+// reference's exact Sphere.is_hit on that short list instead of the scan over all spheres — same ascending
+// order, same strict '<', so the same closest hit bit for bit — and shades the first hit.  The megakernel
+// takes the paths over from the records written here (its scan then only ever sees scattered rays).
+//
+// The set: a camera ray is the line through O + off and F (camera.zig:99-106), off in the lens disk
+// (|off| <= Rl), F = llc + s*horizontal + t*vertical within the pixel's (s, t) box, i.e. |F - F0| <= Rp
+// around the box centre F0.  Its point at parameter tau, (1 - tau)(O + off) + tau F, lies within
+//   rho(tau) = |1 - tau| Rl + tau (Rp + e_d) + e_o        (tau >= 0)
+// of the central line's point O + tau (F0 - O); e_o, e_d bound the f32 rounding of origin and direction.
+// A sphere (c, r) the ray hits has a point of the ray at distance r from c, so
+//   |c - O - tau Dv| <= r' + rho(tau)   for some tau >= 0,   Dv = F0 - O,
+// r'^2 = r^2 + g (2 (|c - O| + Rl)^2 + r^2) covering the rounding of the f32 discriminant (sphere.zig:66-72).
+// rho is linear on [0,1] and on [1,inf): on each piece the condition is a quadratic in tau, minimised in
+// closed form.  Evaluated in double.  Rays behind tau = 0 do not exist (the list is used for t_min >= 0 only).
+struct ListCam {
+    double O[3], llc[3], H[3], V[3];
+    double Rl, Rp, e_o, e_d;
+};
+constexpr double kListGamma = 4e-6; // >= 9x the rounding bound of the f32 discriminant: 2^-24 (14 |oc|^2 + 6 r^2) a
+
+__device__ __forceinline__ bool list_piece(double DD, double xx, double xd, double R, double beta, double ta, double tb) {
+    const double A = DD - beta * beta;
+    if (!(A > 0.0)) return true; // degenerate camera (footprint wider than the focal distance): keep the sphere
+    const double Bh = xd + R * beta;
+    double tm = Bh / A;
+    tm = fmin(fmax(tm, ta), tb);
+    const double g = (A * tm - 2.0 * Bh) * tm + xx - R * R;
+    return g <= 1e-9 * (xx + R * R + DD * tm * tm);
+}
+
+__global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_t width, uint32_t height, uint32_t slot0, uint32_t npix,
+                                                        uint32_t idx_start, uint32_t idx_stop, uint32_t tile_pixels, uint32_t tile_count,
+                                                        uint32_t tile_index, const float4 *__restrict__ geom, uint32_t nspheres,
+                                                        uint32_t *__restrict__ lists) {
+    const uint32_t po = blockIdx.x * 256u + threadIdx.x;
+    if (po >= npix) return;
+    uint32_t *L = lists + (size_t)po * kListCap;
+    const uint32_t pixel = slot_to_pixel(slot0 + po, idx_start, tile_pixels, tile_count, tile_index);
+    if (pixel >= idx_stop) { L[0] = kListEnd; return; }
+    const uint32_t col = pixel % width, row = pixel / width;
+    // the (s, t) box of renderers/ppm_image.zig:61-62 (sic: +1 in v), centre
+    const double sm = ((double)col + 0.5) / (double)width;
+    const double tm = ((double)(height - row + 1u) + 0.5) / (double)height;
+    double Dv[3], DD = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        Dv[i] = C.llc[i] + sm * C.H[i] + tm * C.V[i] - C.O[i];
+        DD += Dv[i] * Dv[i];
+    }
+    const double a1 = C.Rl + C.e_o, b1 = (C.Rp + C.e_d) - C.Rl;   // tau in [0, 1]
+    const double a2 = C.e_o - C.Rl, b2 = (C.Rp + C.e_d) + C.Rl;   // tau in [1, inf)
+    // Quick reject, cheap and conservative, before the two quadratic tests: rho(tau) <= a1 + b2 tau; a sphere
+    // touched at tau has tau |Dv| <= |x| + r' + rho(tau), i.e. tau <= tau_hi = (|x| + r' + a1) / (|Dv| - b2); and
+    // its centre is no further from the central LINE than r' + a1 + b2 tau_hi.  Upper bounds in f32 (inflated),
+    // the distance to the line in double.
+    const double invDD = 1.0 / DD;
+    const float lenD = (float)sqrt(DD) * (1.0f - 1e-6f) - (float)b2 * (1.0f + 1e-6f);
+    const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-6f) / lenD : 0.0f;
+    const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f), Rlf = (float)C.Rl * (1.0f + 1e-6f);
+    uint32_t count = 0;
+    for (uint32_t j = 0; j < nspheres; ++j) {
+        const float4 g = geom[j]; // (cx, cy, cz, radius): wave-uniform address
+        const double x0 = (double)g.x - C.O[0], x1 = (double)g.y - C.O[1], x2 = (double)g.z - C.O[2];
+        const double xx = x0 * x0 + x1 * x1 + x2 * x2;
+        const double xd = x0 * Dv[0] + x1 * Dv[1] + x2 * Dv[2];
+        if (lenD > 0.0f) {
+            const float xl = sqrtf((float)xx) * (1.0f + 1e-6f);           // >= |x|
+            const float xr = xl + Rlf;
+            const float rub = (fabsf(g.w) + sqrtf((float)kListGamma * (2.0f * xr * xr + g.w * g.w))) * (1.0f + 1e-5f); // >= r'
+            const float tau_hi = (xl + rub + a1f) * inv_lenD * (1.0f + 1e-5f);
+            const float Rmax = (rub + a1f + b2f * tau_hi) * (1.0f + 1e-5f);
+            if (xx - xd * xd * invDD > (double)Rmax * (double)Rmax) continue;
+        }
+        const double r2 = (double)g.w * (double)g.w;
+        const double xl = sqrt(xx) + C.Rl;
+        const double reff = sqrt(r2 + kListGamma * (2.0 * xl * xl + r2));
+        if (list_piece(DD, xx, xd, reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, reff + a2, b2, 1.0, 1e300)) {
+            if (count < kListCap) L[count] = j;
+            count++;
+        }
+    }
+    if (count > kListCap) L[0] = kListOverflow;  // too many: this pixel's camera rays take the scan
+    else if (count < kListCap) L[count] = kListEnd;
+}
+
+// One thread per path of the launch, in record order (item-major, the item's samples consecutive): the
+// camera ray (renderers/ppm_image.zig:50-51,61-63), Scene.is_hit over the pixel's list, one radiance step
+// (illumination.zig:76-90 at depth 0).
+template <bool DET>
+__global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
+    // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
+    // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
+    uint32_t rays = 0, cands = 0, not_unit = 0;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
+        const uint32_t item = r / P.chunk, jj = r - item * P.chunk;
+        const uint32_t k = item / P.npix, po = item - k * P.npix;
+        const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
+        const uint32_t first = P.s0 + k * P.chunk;
+        const uint32_t sample = first + jj;
+        if (pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
+            typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
+            rng.init(P.seed_lo, P.seed_hi);
+            rng.start_path(pixel, sample);
+            const uint32_t i_col = pixel % P.width;
+            const uint32_t i_row = pixel / P.width;
+            float xi_u, xi_v;
+            rng.next2(xi_u, xi_v);
+            const float u = ((float)i_col + xi_u) / (float)P.width;
+            const float v = ((float)(P.height - i_row + 1u) + xi_v) / (float)P.height;
+            const V3 disk = random_vector_in_unit_disk(rng);
+            V3 o, d;
+            cast_ray_from_disk(P.cam, u, v, disk, o, d);
+            const uint32_t *L = P.lists + (size_t)po * kListCap;
+            // a disk draw kept after PT_MAX_TRIES failed tries may lie outside the lens the list was built for
+            const bool listed = L[0] != kListOverflow && vlen2(disk) < 1.0f;
+            float4 ra, rb;
+            if (!listed) {
+                ra = make_float4(o.x, o.y, o.z, __uint_as_float(kTagState0 << 30));
+                rb = make_float4(d.x, d.y, d.z, __uint_as_float(rng.drawn()));
+            } else {
+                const float a = vlen2(d); // sphere.zig:68
+                float closest = P.t_max;
+                int hit = -1;
+                for (uint32_t i = 0; i < kListCap; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
+                    const uint32_t j = L[i];
+                    if (j == kListEnd) break;
+                    const float4 g = P.geom[j];
+                    cands++;
+                    float t;
+                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
+                        if (t < closest) { closest = t; hit = (int)j; }
+                    }
+                }
+                rays++;
+                const float d_len = sqrtf(a);
+                V3 color = v3(0.f, 0.f, 0.f);
+                uint32_t tag = kTagFinal;
+                ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra;
+                if (hit >= 0) {
+                    if (P.illum != PT_ILLUM_RADIANCE) {
+                        if (P.illum == PT_ILLUM_NORMAL) { // illumination.zig:45-47; sic: about the constant centre (0,0,-1)
+                            const V3 p = vadd(o, vmul(d, closest));
+                            const V3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
+                            color = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
+                        } else {                          // illumination.zig:65-69
+                            const float4 m = P.mat[hit];
+                            color = (P.kind[hit] == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
+                        }
+                    } else if (P.rebounds != 0u) {        // rebounds == 0: illumination.zig:80-81, black
+                        const float4 g = P.geom[hit];
+                        const float4 m = P.mat[hit];
+                        V3 p, n;
+                        sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, P.inv_radius[hit], p, n);
+                        const V3 nd = scatter_pre(P.kind[hit], m.w, m.x, m.y, d_len, d, p, n, rng);
+                        tag = kTagState1;
+                        ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState1 << 30) | (uint32_t)hit));
+                        rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(rng.drawn()));
+                    }
+                } else if (!lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color)) { // illumination.zig:88
+                    tag = kTagSkip;
+                    not_unit++;
+                }
+                if (tag != kTagState1) ra = make_float4(color.x, color.y, color.z, __uint_as_float(tag << 30));
+            }
+            P.rec_a[r] = ra;
+            if (__float_as_uint(ra.w) >> 31) P.rec_b[r] = rb;
+        }
+    }
+    const unsigned long long w_rays = wave_sum_u64(rays), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
+    if ((threadIdx.x & 63u) == 0u) {
+        if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
+        if (w_cands) atomicAdd(&P.counters[CNT_CANDS], w_cands);
+        if (w_nu) atomicAdd(&P.counters[CNT_NOT_UNIT], w_nu);
     }
 }
 
@@ -797,6 +1023,9 @@ struct ptgpu_ctx {
     int resident[2][2] = {{0, 0}, {0, 0}};           // [det][multi]: workgroups per CU the occupancy query reports
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
     uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
+    uint64_t primary_cap = 24ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
+    unsigned char *d_prim = nullptr; size_t prim_bytes = 0; // primary-pass records + candidate lists
+    hipEvent_t evp0 = nullptr, evp1 = nullptr;       // around the primary pass of a one-segment render
     pt_stats stats;
 };
 
@@ -858,15 +1087,18 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evp0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evp1);
     // this device's address of the static scratch array (device `device` is current here)
     if (e == hipSuccess) e = hipGetSymbolAddress((void **)&ctx->d_scratch, HIP_SYMBOL(scratch));
     if (e == hipSuccess) {
         // workgroups per CU each kernel variant can keep resident (the persistent grid's size)
         int r = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][1] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
+        // (the variants that start paths from primary-pass records have the same launch bounds and LDS)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
     }
     if (e != hipSuccess || !ctx->d_scratch) {
@@ -875,6 +1107,8 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
         if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+        if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
+        if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
         delete ctx;
         return PT_ERR_HIP;
     }
@@ -887,12 +1121,14 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
 extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PT_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters};
+    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters, ctx->d_prim};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
+    if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
     delete ctx;
     return PT_OK;
 }
@@ -926,6 +1162,9 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
     case PT_LIMIT_PARTIAL_BYTES:
         if (value < 4096) return PT_ERR_BAD_ARG;
         ctx->partial_cap = value;
+        return PT_OK;
+    case PT_LIMIT_PRIMARY_BYTES:
+        ctx->primary_cap = value;
         return PT_OK;
     default: return PT_ERR_BAD_ARG;
     }
@@ -1051,6 +1290,33 @@ static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, u
     return PT_OK;
 }
 
+// Host side of pt_primary_lists (see its comment): the camera in double, the lens and footprint radii, the
+// rounding allowances.
+static ListCam make_list_cam(const Cam &c, uint32_t width, uint32_t height) {
+    ListCam L;
+    const V3 *src[4] = {&c.lookfrom, &c.llc, &c.horizontal, &c.vertical};
+    double *dst[4] = {L.O, L.llc, L.H, L.V};
+    double len[4];
+    for (int i = 0; i < 4; ++i) {
+        dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z;
+        len[i] = sqrt(dst[i][0] * dst[i][0] + dst[i][1] * dst[i][1] + dst[i][2] * dst[i][2]);
+    }
+    // |u*x + v*y| <= sigma_max([u v]) |(x, y)|: largest eigenvalue of the 2x2 Gram matrix
+    const double uu = (double)c.u.x * c.u.x + (double)c.u.y * c.u.y + (double)c.u.z * c.u.z;
+    const double vv = (double)c.v.x * c.v.x + (double)c.v.y * c.v.y + (double)c.v.z * c.v.z;
+    const double uv = (double)c.u.x * c.v.x + (double)c.u.y * c.v.y + (double)c.u.z * c.v.z;
+    const double lam = 0.5 * ((uu + vv) + sqrt((uu - vv) * (uu - vv) + 4.0 * uv * uv));
+    const double ulp = 5.9604644775390625e-08; // 2^-24
+    L.Rl = fabs((double)c.lens_radius) * sqrt(lam) * (1.0 + 1e-6);
+    // (col + xi) and (height - row + 1 + xi) are rounded to f32 before the division: up to an ulp of the index outside the box
+    const double wh = (double)(width > height ? width : height);
+    L.Rp = 0.5 * (len[2] / (double)width + len[3] / (double)height) * (1.0 + 1e-3 + 8.0 * wh * ulp);
+    const double mag = len[0] + len[1] + len[2] + len[3] + L.Rl;
+    L.e_o = 16.0 * ulp * (len[0] + L.Rl);
+    L.e_d = 32.0 * ulp * mag;
+    return L;
+}
+
 // Device memory a render works in besides its inputs and output.
 struct Workspace {
     unsigned long long *counters; // CNT_N
@@ -1058,14 +1324,19 @@ struct Workspace {
     float *part; size_t part_bytes;
 };
 
-static void launch_megakernel(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+template <bool PRIMARY>
+static void launch_megakernel_p(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
     if (det) {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<true, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
     } else {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, P);
+        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<false, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
     }
+}
+static void launch_megakernel(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+    if (P.primary) launch_megakernel_p<true>(det, multi, grid, stream, P);
+    else launch_megakernel_p<false>(det, multi, grid, stream, P);
 }
 
 // The render behind both ptgpu_render_sum_device (workspace from hipMalloc, grown on demand) and
@@ -1117,25 +1388,40 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         ws.part = nullptr;
         part_avail = (size_t)ctx->partial_cap;
     }
-    // segment = pixel slots traced per launch
-    uint32_t seg = npix;
-    if (nchunks > 1) {
-        const uint64_t per_slot = (uint64_t)nchunks * 3u * sizeof(float);
-        const uint64_t fit = part_avail / per_slot;
-        if (fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
-        if (fit < seg) seg = (uint32_t)(fit / 64u * 64u);
-        // u32 item ids incl. the waves' last (overshooting) reservations
+    // segment = pixel slots traced per launch: bounded by the partial buffer and, with the primary pass, by
+    // the buffer of its records (32 B per path) and candidate lists
+    auto fit_slots = [](uint64_t avail, uint64_t per_slot) -> uint64_t { return per_slot ? avail / per_slot : ~0ull; };
+    const uint64_t part_per_slot = (nchunks > 1) ? (uint64_t)nchunks * 3u * sizeof(float) : 0u;
+    const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListCap * sizeof(uint32_t);
+    // the lists hold rays that leave the lens forwards; the no-allocation entry point keeps the camera rays in the megakernel
+    bool primary = !noalloc && cfg->t_min >= 0.0f && ctx->primary_cap != 0 && fit_slots(ctx->primary_cap - std::min<uint64_t>(ctx->primary_cap, 1024u), prim_per_slot) >= 64;
+    uint64_t fit = fit_slots(part_avail, part_per_slot);
+    if (fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
+    if (primary) fit = std::min(fit, fit_slots(ctx->primary_cap - 1024u, prim_per_slot));
+    uint64_t seg64 = npix;
+    if (fit < seg64) seg64 = fit / 64u * 64u;
+    {   // u32 item ids incl. the waves' last (overshooting) reservations; u32 record ids
         const uint64_t max_items = 0xf0000000ull;
-        if ((uint64_t)seg * nchunks > max_items) seg = (uint32_t)(max_items / nchunks / 64u * 64u);
-        if (seg == 0) return PT_ERR_BAD_ARG;
-        const size_t part_need = (size_t)seg * per_slot;
+        if (seg64 * nchunks > max_items) seg64 = max_items / nchunks / 64u * 64u;
+        if (primary && seg64 * nchunks * chunk > max_items) seg64 = max_items / ((uint64_t)nchunks * chunk) / 64u * 64u;
+        if (seg64 == 0) return PT_ERR_BAD_ARG;
+    }
+    const uint32_t seg = (uint32_t)seg64;
+    if (nchunks > 1) {
+        const size_t part_need = (size_t)seg * part_per_slot;
         if (noalloc) ws.part_bytes = part_need;
         else {
             rc = ensure(ctx, (void **)&ctx->d_part, &ctx->part_bytes, part_need);
             if (rc != PT_OK) return rc;
             ws.part = ctx->d_part; ws.part_bytes = ctx->part_bytes;
         }
-    } else if ((uint64_t)npix > 0xf0000000ull) return PT_ERR_BAD_ARG;
+    }
+    const size_t nrec_seg = (size_t)seg * nchunks * chunk;
+    const size_t rec_half = (nrec_seg * 16u + 255u) & ~(size_t)255u;
+    if (primary) {
+        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, 2u * rec_half + (size_t)seg * kListCap * sizeof(uint32_t));
+        if (rc != PT_OK) return rc;
+    }
 
     KParams P;
     P.cam = ctx->cam;
@@ -1155,6 +1441,13 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
+    P.primary = primary ? 1u : 0u;
+    P.rec_a = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
+    P.rec_b = primary ? reinterpret_cast<float4 *>(ctx->d_prim + rec_half) : nullptr;
+    uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + 2u * rec_half) : nullptr;
+    P.lists = d_lists;
+    const ListCam LC = primary ? make_list_cam(ctx->cam, cfg->width, cfg->height) : ListCam{};
+    const bool one_seg = seg >= npix;
 
     HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -1163,9 +1456,22 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         P.slot0 = slot0;
         P.npix = std::min(seg, npix - slot0);
         if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
+        if (primary) {
+            if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->evp0, stream));
+            hipLaunchKernelGGL(pt_primary_lists, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
+                               cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const float4 *)ctx->d_geom,
+                               ctx->nspheres, d_lists);
+            HIP_TRY(ctx, hipGetLastError());
+            const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
+            const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);
+            if (det) hipLaunchKernelGGL((pt_primary<true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+            else hipLaunchKernelGGL((pt_primary<false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+            HIP_TRY(ctx, hipGetLastError());
+            if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->evp1, stream));
+        }
         launch_megakernel(det, multi, grid, stream, P);
         HIP_TRY(ctx, hipGetLastError());
-        if (slot0 == 0 && seg >= npix) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // one segment: ev0..ev1 is the megakernel alone
+        if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // one segment: ev0..ev1 is the tracing kernels alone
         if (nchunks > 1) {
             const uint32_t n3 = P.npix * 3u;
             hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)ws.part, slot0, P.npix, nchunks,
@@ -1185,6 +1491,13 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     ctx->stats.rays = h[CNT_RAYS];
     ctx->stats.sphere_tests = h[CNT_RAYS] * ctx->nspheres;
     ctx->stats.candidates = h[CNT_CANDS];
+    ctx->stats.primary_rays = h[CNT_PRIMARY_RAYS];
+    ctx->stats.primary_ms = 0.0;
+    if (primary && nseg == 1) {
+        float msp = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&msp, ctx->evp0, ctx->evp1));
+        ctx->stats.primary_ms = msp;
+    }
     ctx->stats.not_unit = h[CNT_NOT_UNIT];
 #ifdef PT_PHASE_TIMING
     {

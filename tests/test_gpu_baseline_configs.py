@@ -174,6 +174,35 @@ def test_convergence_psnr_4096spp(orc, gpu):
     assert psnr >= 40.0, psnr
 
 
+def test_convergence_against_the_reference_sampler(orc, gpu):
+    """North star: "the stochastic output must converge to the reference's image at high spp (>= 40 dB at 4096 spp)".
+    The GPU's 4096-path frame (Philox streams) against the REFERENCE'S OWN SAMPLER — main.zig:166-177's single-thread
+    render() drawing u, v and the lens offsets from the sequential std.rand stream that built the scene and the
+    scatters from material.zig:15's module-level DefaultPrng.init(0), restated by orc_render_sum_zig.  Two unbiased
+    estimators of one image: mse = sigma^2 (1/4096 + 1/n), so the PSNR must clear 40 dB and must RISE with n
+    (measured on the CPU with the bit-identical oracle: 1024 / 2048 / 4096 reference paths -> 48.0 / 50.7 / 52.0 dB;
+    a bias from the generator swap would show as a floor).  Tolerance: >= 40 dB at n = 1024, >= +3 dB from n = 256
+    (expected 10 log10(17/5) = 5.3)."""
+    host, scene, cam = _setup(gpu, 21, 456)
+    img = host.Image(48)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=1024, rebounds=50)
+    g = gpu.render_mean(host.make_pt_config(img, rt, seed=1)).astype(np.float64)
+    ocam = orc.Camera()
+    C.memmove(C.byref(ocam), C.byref(cam.pod), C.sizeof(ocam))
+    oimg = orc.image_new(48)
+    psnr = {}
+    for rps in (64, 256):
+        spheres, stream = orc.setup_scene(21, 456)      # the stream continues from the scene set-up (main.zig:100,173)
+        np.testing.assert_array_equal(spheres, scene.spheres)
+        ocfg = orc.make_config(oimg, subpixels=4, rays_per_subsample=rps, rebounds=50, mode=2)
+        rc, s, st = orc.render_sum_zig(spheres, ocam, ocfg, stream)
+        assert rc == 0 and st.paths == 48 * 27 * 4 * rps
+        z = orc.resolve_mean(ocfg, s).astype(np.float64)
+        psnr[4 * rps] = 10.0 * np.log10(1.0 / float(np.mean((g - z) ** 2)))
+    assert psnr[1024] >= 40.0, psnr
+    assert psnr[1024] >= psnr[256] + 3.0, psnr
+
+
 @pytest.mark.parametrize("deterministic", [True, False])
 def test_config2_full_hd_frame_against_oracle(orc, gpu, deterministic):
     """configs[2]'s frame (scene 21, 1920x1080, depth 50) at 4 paths per pixel: every one of the 2 073 600

@@ -310,3 +310,26 @@ def test_zig_mode_render_runs(orc):
     assert rc == 0 and st.paths == 24 * 13 * 2
     mean = out / 2.0
     assert 0.0 <= mean.min() and mean.max() <= 1.0 and mean[0].mean() > mean[-1].mean() * 0.8
+
+
+def test_philox_streams_converge_to_the_reference_sampler(orc):
+    """The generator swap is unbiased: the Philox-stream estimate (what the GPU computes, bit for bit) and the
+    reference's own sequential std.rand sampler (orc_render_sum_zig: main.zig:166-177 + material.zig:15) agree
+    better the more paths either takes.  24x13 pixels of scene 21, depth 50; the GPU-side test at 48x27 / 4096 paths
+    is tests/test_gpu_baseline_configs.py::test_convergence_against_the_reference_sampler."""
+    cam = orc.camera_preset(21)
+    img = orc.image_new(24)
+    sp, _ = orc.setup_scene(21, 456)
+    cfgp = orc.make_config(img, subpixels=4, rays_per_subsample=256, rebounds=50, seed=1, chunk=16)
+    rc, s, _ = orc.render_sum(sp, cam, cfgp, 8)
+    assert rc == 0
+    p = orc.resolve_mean(cfgp, s).astype(np.float64)
+    psnr = {}
+    for rps in (16, 256):
+        sp2, stream = orc.setup_scene(21, 456)
+        cfg = orc.make_config(img, subpixels=4, rays_per_subsample=rps, rebounds=50, mode=2)
+        rc, z, st = orc.render_sum_zig(sp2, cam, cfg, stream)
+        assert rc == 0 and st.paths == 24 * 13 * 4 * rps
+        z = orc.resolve_mean(cfg, z).astype(np.float64)
+        psnr[4 * rps] = 10.0 * np.log10(1.0 / float(np.mean((p - z) ** 2)))
+    assert psnr[1024] >= 36.0 and psnr[1024] >= psnr[64] + 6.0, psnr  # expected gain 10 log10(17/2) = 9.3 dB
