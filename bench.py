@@ -34,11 +34,12 @@ def algorithmic_flops(paths, rays, nspheres):
     return rays * nspheres * 18.0 + rays * 60.0 + paths * 40.0
 
 
-def executed_flops(paths, rays, nspheres, shared_tests):
-    """What the shipped kernel executes per ray-sphere test: 7 FMA + 1 compare (15 FLOP) on every lane, or 5 FMA + 1
-    compare (11 FLOP) for the `shared_tests` spheres in shared-ordinate mask words; the exact test runs on the
-    filter's survivors only (inside the per-ray term)."""
-    return rays * ((nspheres - shared_tests) * 15.0 + shared_tests * 11.0) + rays * 60.0 + paths * 40.0
+def executed_flops(paths, rays, nspheres, shared_tests, primary_rays=0):
+    """What the shipped kernels execute: per ray-sphere test of the SCAN 7 FMA + 1 compare (15 FLOP) on every lane, or
+    5 FMA + 1 compare (11 FLOP) for the `shared_tests` spheres in shared-ordinate mask words; the exact test runs on the
+    filter's survivors only (inside the per-ray term).  `primary_rays` camera rays never enter the scan: the primary
+    pass gives them the exact test on their pixel's candidate list (per-ray term only)."""
+    return (rays - primary_rays) * ((nspheres - shared_tests) * 15.0 + shared_tests * 11.0) + rays * 60.0 + paths * 40.0
 
 
 def cpu_baseline(width, depth, seed):
@@ -144,13 +145,16 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, paths, rays, wave_steps = [], 0, 0, 0
+    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, segments = [], [], 0, 0, 0, 0, 0
     for _ in range(args.steps):
         st = step()
-        kernel_ms.append(st.kernel_ms)   # HIP events around the megakernel, on the stream it ran on
+        kernel_ms.append(st.kernel_ms)   # HIP events around the tracing kernels (primary pass + megakernel), on the stream they ran on
+        primary_ms.append(st.primary_ms) # ... around the primary pass alone (0 when the render took several segments)
         paths += st.paths
         rays += st.rays
         wave_steps += st.wave_steps
+        primary_rays += st.primary_rays
+        segments = st.segments
     fence()
     dt = time.perf_counter() - t0
 
@@ -170,8 +174,15 @@ def main():
                       else "scene 21 (488 spheres, seed %d)" % args.seed)
         headline = args.spheres == 0 and args.width == 1920 and args.spp == 256 and args.depth == 50
         k_ms = sum(kernel_ms) / len(kernel_ms)
+        p_ms = sum(primary_ms) / len(primary_ms)
         flops_per_launch = algorithmic_flops(paths / args.steps, rays / args.steps, nsph)
         achieved = flops_per_launch / (k_ms * 1e-3)
+        shared = gpu.scene_info()["shared_ordinate_tests"]
+        mega = {}
+        if p_ms > 0:  # the megakernel alone: the scattered rays it scans, over its own time
+            scan_rays = (rays - primary_rays) / args.steps
+            mega = {"megakernel_ms": k_ms - p_ms, "primary_pass_ms": p_ms,
+                    "megakernel_frac": (scan_rays * (nsph * 18.0 + 60.0)) / ((k_ms - p_ms) * 1e-3) / PEAK_FP32_VALU}
         out = {
             "metric": "paths/sec (scene 21, 1920x1080, 1024 spp, depth 50)" if headline else
                       "paths/sec (%s, %dx%d, %d spp, depth %d)" % (scene_name, img.width, img.height, 4 * args.spp, args.depth),
@@ -192,18 +203,26 @@ def main():
             "rays_per_path": all_rays / all_paths,
             "roofline": {"bound": "valu", "achieved": achieved * 1e-12, "peak": PEAK_FP32_VALU * 1e-12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU, "traffic": None,
-                         "kernel": "pt_megakernel", "kernel_ms": k_ms,
+                         "kernel": "pt_primary_lists + pt_primary + pt_megakernel (the render's tracing kernels)" if primary_rays else "pt_megakernel",
+                         "kernel_ms": k_ms, "segments": segments,
                          "flops_per_launch": flops_per_launch,
                          "rays_per_launch": rays / args.steps, "wave_steps_per_launch": wave_steps / args.steps,
-                         "spheres": nsph, "shared_ordinate_tests": gpu.scene_info()["shared_ordinate_tests"],
+                         "primary_rays_per_launch": primary_rays / args.steps,
+                         "spheres": nsph, "shared_ordinate_tests": shared,
                          "basis": "algorithmic",
-                         "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph, gpu.scene_info()["shared_ordinate_tests"])
+                         "executed_frac": executed_flops(paths / args.steps, rays / args.steps, nsph, shared, primary_rays / args.steps)
                                           / (k_ms * 1e-3) / PEAK_FP32_VALU,
+                         **mega,
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d). `achieved`/`frac` price the "
-                                 "ALGORITHMIC work of the reference's scan: 18 FLOP/ray-sphere test + 60/ray + 40/path over the "
-                                 "device-counted rays of rank 0's launch — an algorithmic-work rate, not hardware utilisation. "
-                                 "`executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP; 5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words); "
-                                 "issue-slot utilisation from the SQ counters is in profiles/"},
+                                 "ALGORITHMIC work of the reference's scan — 18 FLOP/ray-sphere test + 60/ray + 40/path for EVERY "
+                                 "device-counted ray of rank 0's render — over the HIP-event time of its tracing kernels: an "
+                                 "algorithmic-work rate, not hardware utilisation.  `primary_rays_per_launch` camera rays are resolved "
+                                 "by the primary pass against their pixel's candidate list instead of the scan (same closest hit, bit "
+                                 "for bit), which is why `frac` can pass what VALU issue alone would allow.  `executed_frac` prices "
+                                 "what the kernels execute: scattered rays x (7 FMA + 1 compare = 15 FLOP per test; 5 FMA + 1 compare "
+                                 "= 11 for spheres in shared-ordinate mask words) + 60/ray + 40/path; `megakernel_frac` is the "
+                                 "algorithmic rate of the megakernel alone (the rays it scans over its own time), the figure "
+                                 "comparable with earlier rounds' `frac`.  Issue-slot utilisation from the SQ counters is in profiles/"},
         }
         if args.rehearse_gloo:
             out["rehearsal"] = "all ranks on ONE GPU over gloo: plumbing check only, not a benchmark result"

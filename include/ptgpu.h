@@ -132,7 +132,7 @@ typedef struct pt_stats {
     double total_ms;       /* kernel + chunk sums                                    */
     uint64_t segments;     /* megakernel launches the render took (PT_LIMIT_PARTIAL_BYTES, PT_LIMIT_PRIMARY_BYTES) */
     uint64_t primary_rays; /* of `rays`: camera rays whose closest hit came from their pixel's candidate list (primary pass), not from the scan */
-    double primary_ms;     /* of kernel_ms: the primary pass (candidate lists + camera rays + first radiance step); 0 when segments > 1 */
+    double primary_ms;     /* of kernel_ms: the primary pass (candidate lists + camera rays + first radiance step), summed over the segments (0 beyond 64 segments) */
 } pt_stats;
 
 typedef struct ptgpu_ctx ptgpu_ctx;

@@ -102,7 +102,8 @@ struct KParams {
     float *part;        // direct ? frame[W*H][3] : [nchunks][npix][3] partial sums
     // primary pass (pt_primary): one record per path of the launch, index item * chunk + (sample - item's first sample)
     uint32_t primary;       // 1: the records exist; the megakernel starts its paths from them instead of casting camera rays
-    float4 *rec_a, *rec_b;  // (colour | origin, tag<<30 | first hit id), (direction, draws taken)
+    float4 *rec;            // record r = rec[2r], rec[2r+1]: (colour | origin, tag<<30 | first hit id), (direction, draws taken) — 32 B, so that
+                            // the two halves share a cache line and a line holds a lane's next record too
     const uint32_t *lists;  // [npix][kListCap]: candidate spheres of each pixel slot's camera rays (pt_primary_lists)
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
@@ -454,11 +455,10 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             if (alive && need_path && sample != s_end) {
                 for (;;) {
                     const uint32_t r = rec_base + sample;
-                    const float4 ra = P.rec_a[r];
+                    const float4 ra = P.rec[2u * (size_t)r], rb = P.rec[2u * (size_t)r + 1u]; // both halves at once: one round trip
                     const uint32_t meta = __float_as_uint(ra.w);
                     const uint32_t tag = meta >> 30;
                     if (tag >= kTagState0) {
-                        const float4 rb = P.rec_b[r];
                         o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
                         rng.resume(pixel, sample, __float_as_uint(rb.w));
                         bounce = tag - kTagState0; // 0: camera ray, 1: after the first bounce
@@ -640,9 +640,31 @@ __device__ __forceinline__ bool list_piece(double DD, double xx, double xd, doub
     return g <= 1e-9 * (xx + R * R + DD * tm * tm);
 }
 
+// Per sphere, what pt_primary_lists needs and no pixel changes: x = c - O, |x|^2, r', and f32 upper bounds of
+// |x| and r' for the quick reject.
+struct ListSphere {
+    double x[3], xx, reff;
+    float xl, rub;
+};
+__global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float4 *__restrict__ geom, uint32_t nspheres, ListSphere *__restrict__ out) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= nspheres) return;
+    const float4 g = geom[j]; // (cx, cy, cz, radius)
+    ListSphere S;
+    S.x[0] = (double)g.x - C.O[0]; S.x[1] = (double)g.y - C.O[1]; S.x[2] = (double)g.z - C.O[2];
+    S.xx = S.x[0] * S.x[0] + S.x[1] * S.x[1] + S.x[2] * S.x[2];
+    const double r2 = (double)g.w * (double)g.w;
+    const double xl = sqrt(S.xx) + C.Rl;
+    S.reff = sqrt(r2 + kListGamma * (2.0 * xl * xl + r2));
+    S.xl = sqrtf((float)S.xx) * (1.0f + 1e-6f);                  // >= |x|
+    const float xr = S.xl + (float)C.Rl * (1.0f + 1e-6f);
+    S.rub = (fabsf(g.w) + sqrtf((float)kListGamma * (2.0f * xr * xr + g.w * g.w))) * (1.0f + 1e-5f); // >= r'
+    out[j] = S;
+}
+
 __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_t width, uint32_t height, uint32_t slot0, uint32_t npix,
                                                         uint32_t idx_start, uint32_t idx_stop, uint32_t tile_pixels, uint32_t tile_count,
-                                                        uint32_t tile_index, const float4 *__restrict__ geom, uint32_t nspheres,
+                                                        uint32_t tile_index, const ListSphere *__restrict__ sph, uint32_t nspheres,
                                                         uint32_t *__restrict__ lists) {
     const uint32_t po = blockIdx.x * 256u + threadIdx.x;
     if (po >= npix) return;
@@ -666,26 +688,20 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     // the distance to the line in double.
     const double invDD = 1.0 / DD;
     const float lenD = (float)sqrt(DD) * (1.0f - 1e-6f) - (float)b2 * (1.0f + 1e-6f);
-    const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-6f) / lenD : 0.0f;
-    const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f), Rlf = (float)C.Rl * (1.0f + 1e-6f);
+    const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-5f) / lenD : 0.0f;
+    const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f);
     uint32_t count = 0;
     for (uint32_t j = 0; j < nspheres; ++j) {
-        const float4 g = geom[j]; // (cx, cy, cz, radius): wave-uniform address
-        const double x0 = (double)g.x - C.O[0], x1 = (double)g.y - C.O[1], x2 = (double)g.z - C.O[2];
-        const double xx = x0 * x0 + x1 * x1 + x2 * x2;
-        const double xd = x0 * Dv[0] + x1 * Dv[1] + x2 * Dv[2];
+        const ListSphere &S = sph[j]; // wave-uniform address
+        const double xx = S.xx;
+        const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
         if (lenD > 0.0f) {
-            const float xl = sqrtf((float)xx) * (1.0f + 1e-6f);           // >= |x|
-            const float xr = xl + Rlf;
-            const float rub = (fabsf(g.w) + sqrtf((float)kListGamma * (2.0f * xr * xr + g.w * g.w))) * (1.0f + 1e-5f); // >= r'
-            const float tau_hi = (xl + rub + a1f) * inv_lenD * (1.0f + 1e-5f);
-            const float Rmax = (rub + a1f + b2f * tau_hi) * (1.0f + 1e-5f);
+            const float base = S.rub + a1f;
+            const float tau_hi = (S.xl + base) * inv_lenD;
+            const float Rmax = (base + b2f * tau_hi) * (1.0f + 1e-5f);
             if (xx - xd * xd * invDD > (double)Rmax * (double)Rmax) continue;
         }
-        const double r2 = (double)g.w * (double)g.w;
-        const double xl = sqrt(xx) + C.Rl;
-        const double reff = sqrt(r2 + kListGamma * (2.0 * xl * xl + r2));
-        if (list_piece(DD, xx, xd, reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, reff + a2, b2, 1.0, 1e300)) {
+        if (list_piece(DD, xx, xd, S.reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, S.reff + a2, b2, 1.0, 1e300)) {
             if (count < kListCap) L[count] = j;
             count++;
         }
@@ -723,7 +739,11 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             cast_ray_from_disk(P.cam, u, v, disk, o, d);
             const uint32_t *L = P.lists + (size_t)po * kListCap;
             // a disk draw kept after PT_MAX_TRIES failed tries may lie outside the lens the list was built for
+#ifdef PT_EXPERIMENT_TRIES1 // tools/build_variant.sh with -DPT_MAX_TRIES=1: what the rejection loops' retries cost this kernel (timing only, breaks parity)
+            const bool listed = L[0] != kListOverflow;
+#else
             const bool listed = L[0] != kListOverflow && vlen2(disk) < 1.0f;
+#endif
             float4 ra, rb;
             if (!listed) {
                 ra = make_float4(o.x, o.y, o.z, __uint_as_float(kTagState0 << 30));
@@ -773,8 +793,8 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                 }
                 if (tag != kTagState1) ra = make_float4(color.x, color.y, color.z, __uint_as_float(tag << 30));
             }
-            P.rec_a[r] = ra;
-            if (__float_as_uint(ra.w) >> 31) P.rec_b[r] = rb;
+            P.rec[2u * (size_t)r] = ra;
+            if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
         }
     }
     const unsigned long long w_rays = wave_sum_u64(rays), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
@@ -996,6 +1016,7 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
 // hipGetSymbolAddress, with that device current); host code only ever uses that resolved pointer.
 #define PT_SCRATCH_BYTES (128ull << 20)
 static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
+constexpr uint32_t kMaxTimedSegments = 64; // renders of more segments report primary_ms = 0
 constexpr size_t kScratchCounters = 256; // bytes reserved for the CNT_N counters at the start of the scratch
 
 struct ptgpu_ctx {
@@ -1025,7 +1046,8 @@ struct ptgpu_ctx {
     uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
     uint64_t primary_cap = 24ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
     unsigned char *d_prim = nullptr; size_t prim_bytes = 0; // primary-pass records + candidate lists
-    hipEvent_t evp0 = nullptr, evp1 = nullptr;       // around the primary pass of a one-segment render
+    void *d_lsph = nullptr; size_t lsph_bytes = 0;          // ListSphere per sphere (pt_list_prep)
+    std::vector<hipEvent_t> evp;                     // pairs around the primary pass of each segment (grown on demand)
     pt_stats stats;
 };
 
@@ -1087,8 +1109,6 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->evp0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->evp1);
     // this device's address of the static scratch array (device `device` is current here)
     if (e == hipSuccess) e = hipGetSymbolAddress((void **)&ctx->d_scratch, HIP_SYMBOL(scratch));
     if (e == hipSuccess) {
@@ -1107,8 +1127,6 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
         if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-        if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
-        if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
         delete ctx;
         return PT_ERR_HIP;
     }
@@ -1121,14 +1139,13 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
 extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PT_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters, ctx->d_prim};
+    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters, ctx->d_prim, ctx->d_lsph};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-    if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
-    if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
+    for (hipEvent_t e : ctx->evp) (void)hipEventDestroy(e);
     delete ctx;
     return PT_OK;
 }
@@ -1421,6 +1438,8 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     if (primary) {
         rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, 2u * rec_half + (size_t)seg * kListCap * sizeof(uint32_t));
         if (rc != PT_OK) return rc;
+        rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
+        if (rc != PT_OK) return rc;
     }
 
     KParams P;
@@ -1442,8 +1461,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
     P.primary = primary ? 1u : 0u;
-    P.rec_a = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
-    P.rec_b = primary ? reinterpret_cast<float4 *>(ctx->d_prim + rec_half) : nullptr;
+    P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + 2u * rec_half) : nullptr;
     P.lists = d_lists;
     const ListCam LC = primary ? make_list_cam(ctx->cam, cfg->width, cfg->height) : ListCam{};
@@ -1451,15 +1469,28 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
 
     HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    if (primary) {
+        hipLaunchKernelGGL(pt_list_prep, dim3((ctx->nspheres + 255u) / 256u), dim3(256), 0, stream, LC, (const float4 *)ctx->d_geom, ctx->nspheres,
+                           (ListSphere *)ctx->d_lsph);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     uint32_t nseg = 0;
     for (uint32_t slot0 = 0; slot0 < npix; slot0 += seg, ++nseg) {
         P.slot0 = slot0;
         P.npix = std::min(seg, npix - slot0);
         if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
         if (primary) {
-            if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->evp0, stream));
+            const bool timed = nseg < kMaxTimedSegments;
+            if (timed) {
+                while (ctx->evp.size() < 2u * (nseg + 1u)) {
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(ctx, hipEventCreate(&e));
+                    ctx->evp.push_back(e);
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg], stream));
+            }
             hipLaunchKernelGGL(pt_primary_lists, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
-                               cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const float4 *)ctx->d_geom,
+                               cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
                                ctx->nspheres, d_lists);
             HIP_TRY(ctx, hipGetLastError());
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
@@ -1467,7 +1498,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             if (det) hipLaunchKernelGGL((pt_primary<true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
             else hipLaunchKernelGGL((pt_primary<false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
             HIP_TRY(ctx, hipGetLastError());
-            if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->evp1, stream));
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg + 1u], stream));
         }
         launch_megakernel(det, multi, grid, stream, P);
         HIP_TRY(ctx, hipGetLastError());
@@ -1493,10 +1524,12 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     ctx->stats.candidates = h[CNT_CANDS];
     ctx->stats.primary_rays = h[CNT_PRIMARY_RAYS];
     ctx->stats.primary_ms = 0.0;
-    if (primary && nseg == 1) {
-        float msp = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&msp, ctx->evp0, ctx->evp1));
-        ctx->stats.primary_ms = msp;
+    if (primary && nseg <= kMaxTimedSegments) {
+        for (uint32_t i = 0; i < nseg; ++i) {
+            float msp = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&msp, ctx->evp[2u * i], ctx->evp[2u * i + 1u]));
+            ctx->stats.primary_ms += msp;
+        }
     }
     ctx->stats.not_unit = h[CNT_NOT_UNIT];
 #ifdef PT_PHASE_TIMING

@@ -5,17 +5,23 @@ src = "gpurun_out/profile_%s" % tag
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), "profiles/%s_bench_kernel_stats.csv" % tag)
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), "profiles/%s_bench_under_rocprof.json" % tag)
-vals = {}
-for name in ("pmc_valu", "pmc_lds", "pmc_grbm", "pmc_fetch", "pmc_write"):
-    if not os.path.exists(os.path.join(src, name, "p_counter_collection.csv")):
-        continue
-    with open(os.path.join(src, name, "p_counter_collection.csv")) as f:
-        for row in csv.DictReader(f):
-            if "megakernel" not in row["Kernel_Name"]:
-                continue
-            vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-    bench = json.load(open(os.path.join(src, name + ".json")))
-kms = bench["roofline"]["kernel_ms"]
+def collect(kernel):
+    """counter sums over the dispatches whose kernel name contains `kernel` (each pass is one bench run of one launch)"""
+    v, b = {}, None
+    for name in ("pmc_valu", "pmc_lds", "pmc_grbm", "pmc_fetch", "pmc_write"):
+        if not os.path.exists(os.path.join(src, name, "p_counter_collection.csv")):
+            continue
+        with open(os.path.join(src, name, "p_counter_collection.csv")) as f:
+            for row in csv.DictReader(f):
+                if kernel not in row["Kernel_Name"]:
+                    continue
+                v[row["Counter_Name"]] = v.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        b = json.load(open(os.path.join(src, name + ".json")))
+    return v, b
+
+
+vals, bench = collect("pt_megakernel")
+kms = bench["roofline"].get("megakernel_ms", bench["roofline"]["kernel_ms"])  # the megakernel's own time when the primary pass ran
 lines = ["# %s — SQ counters of pt_megakernel (one launch: 1080p, 256 paths/pixel, depth 50)" % tag, "",
          "Collected by tools/collect_profile.sh in separate --pmc passes (no tracing).", "", "| counter | value |", "|---|---|"]
 for k in sorted(vals):
@@ -54,6 +60,18 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
 lines += ["", "| derived | value |", "|---|---|"]
 for k, v in derived.items():
     lines.append("| %s | %.4g |" % (k, v))
-lines += ["", "kernel_ms of the counted launch: %.2f; algorithmic roofline fraction of that run: %.3f" % (kms, bench["roofline"]["frac"])]
+lines += ["", "megakernel ms of the counted launch: %.2f; algorithmic roofline fraction of that run (all tracing kernels): %.3f%s"
+          % (kms, bench["roofline"]["frac"], "; of the megakernel alone: %.3f" % rl["megakernel_frac"] if "megakernel_frac" in rl else "")]
+pv, _ = collect("pt_primary<")
+if pv:
+    paths = rl.get("primary_rays_per_launch", 0.0)
+    lines += ["", "## pt_primary (camera rays against their pixel's candidate list + first radiance step) in the same launch", "",
+              "| counter | value |", "|---|---|"]
+    for k in sorted(pv):
+        lines.append("| %s | %.6g |" % (k, pv[k]))
+    lines += ["", "| derived | value |", "|---|---|",
+              "| VALU wave-instructions per 64 paths | %.4g |" % (pv["SQ_INSTS_VALU"] / max(paths / 64.0, 1.0)),
+              "| VALUUtilization (active lanes per VALU instruction) | %.4g |" % (pv["SQ_THREAD_CYCLES_VALU"] / (pv["SQ_ACTIVE_INST_VALU"] * 64)),
+              "| primary pass ms (lists + pt_primary, HIP events) | %.4g |" % rl.get("primary_pass_ms", float("nan"))]
 open("profiles/%s_megakernel_counters.md" % tag, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
