@@ -88,6 +88,10 @@ pub extern fn ptgpu_multi_render_sum_host(m: *PtMulti, cfg: *const PtConfig, spl
 // no counterpart in the reference: the same render without any device allocation (static 128 MiB scratch per GPU)
 pub extern fn ptgpu_render_sum_device_noalloc(ctx: *PtCtx, cfg: *const PtConfig, d_rgb_sum: [*]f32, stream: ?*anyopaque) c_int;
 pub extern fn ptgpu_noalloc_scratch_bytes() u64;
+// device-memory limits of a context (INTEGRATION.md 4c); PT_LIMIT_PRIMARY_BYTES = 0 switches the primary pass off
+pub const PT_LIMIT_PARTIAL_BYTES: c_int = 0;
+pub const PT_LIMIT_PRIMARY_BYTES: c_int = 1;
+pub extern fn ptgpu_set_limit(ctx: *PtCtx, which: c_int, value: u64) c_int;
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
 pub extern fn ptgpu_abi_version() u32;
 
