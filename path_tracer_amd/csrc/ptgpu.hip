@@ -76,6 +76,33 @@ constexpr uint32_t kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 2u, kTagState1 = 
 
 enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
+// x / d for any u32 x without the ~35-instruction expansion of a run-time integer division: mulhi by a
+// host-computed magic number (the "branch-free" scheme: t = mulhi(x, M); q = (t + ((x - t) >> 1)) >> s).
+struct FastDiv {
+    uint32_t d, M, s;
+    __device__ __forceinline__ uint32_t div(uint32_t x) const {
+        const uint32_t t = __umulhi(x, M);
+        const uint32_t q = (t + ((x - t) >> 1)) >> s;
+        return d == 1u ? x : q;
+    }
+};
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{d, 0u, 0u};
+    if (d <= 1u) { f.d = 1u; return f; }
+    uint32_t fl = 31u;
+    while (!(d >> fl)) --fl;                       // floor(log2 d)
+    if ((d & (d - 1u)) == 0u) { f.s = fl - 1u; return f; } // power of two: M = 0, q = (x >> 1) >> (fl - 1)
+    const uint64_t num = (uint64_t)(1u << fl) << 32;
+    uint32_t pm = (uint32_t)(num / d);
+    const uint32_t rem = (uint32_t)(num - (uint64_t)pm * d);
+    pm += pm;
+    const uint32_t twice = rem + rem;
+    if (twice >= d || twice < rem) pm += 1u;
+    f.M = 1u + pm;
+    f.s = fl;
+    return f;
+}
+
 struct KParams {
     Cam cam;
     V3 blend_start, blend_stop;
@@ -92,6 +119,7 @@ struct KParams {
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
     uint32_t nspheres;
     uint32_t total_threads;
+    FastDiv div_width, div_npix, div_chunk, div_tile; // divisions by width, npix, chunk, tile_pixels
     const float4 *filt; // (cx, cz, threshold, cy) padded to a multiple of kPad
     uint32_t has_shared; // any shared-ordinate word in the scene
     const float *ycy;   // per 32-sphere mask word (padded to whole tiles): the cy all its spheres share, or NaN
@@ -115,6 +143,12 @@ __device__ __forceinline__ uint32_t slot_to_pixel(uint32_t po, uint32_t idx_star
                                                   uint32_t tile_index) {
     if (tile_pixels == 0u) return idx_start + po;
     const uint32_t k = po / tile_pixels, r = po - k * tile_pixels;
+    return idx_start + (k * tile_count + tile_index) * tile_pixels + r;
+}
+__device__ __forceinline__ uint32_t slot_to_pixel(uint32_t po, uint32_t idx_start, uint32_t tile_pixels, uint32_t tile_count,
+                                                  uint32_t tile_index, const FastDiv &div_tile) {
+    if (tile_pixels == 0u) return idx_start + po;
+    const uint32_t k = div_tile.div(po), r = po - k * tile_pixels;
     return idx_start + (k * tile_count + tile_index) * tile_pixels + r;
 }
 
@@ -428,9 +462,9 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     // adds no candidates and no exact-pass iterations to its wave.
                     o = v3(0.f, 0.f, 0.f); d = v3(kNaN, kNaN, kNaN);
                     if (item < total_items) {
-                        const uint32_t k = item / P.npix;
+                        const uint32_t k = P.div_npix.div(item);
                         const uint32_t po = item - k * P.npix;
-                        pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
+                        pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
                         sample = P.s0 + k * P.chunk;
                         if (PRIMARY) rec_base = item * P.chunk - sample;
                         s_end = min(sample + P.chunk, P.s1);
@@ -477,8 +511,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         } else if (alive && need_path && sample != s_end) {
             // renderers/ppm_image.zig:50-51,61-63
             rng.start_path(pixel, sample);
-            const uint32_t i_col = pixel % P.width;
-            const uint32_t i_row = pixel / P.width;
+            const uint32_t i_row = P.div_width.div(pixel);
+            const uint32_t i_col = pixel - i_row * P.width;
             float xi_u, xi_v;
             rng.next2(xi_u, xi_v);
             const float u = ((float)i_col + xi_u) / (float)P.width;
@@ -719,17 +753,17 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
     uint32_t rays = 0, cands = 0, not_unit = 0;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
-        const uint32_t item = r / P.chunk, jj = r - item * P.chunk;
-        const uint32_t k = item / P.npix, po = item - k * P.npix;
-        const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index);
+        const uint32_t item = P.div_chunk.div(r), jj = r - item * P.chunk;
+        const uint32_t k = P.div_npix.div(item), po = item - k * P.npix;
+        const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
         const uint32_t first = P.s0 + k * P.chunk;
         const uint32_t sample = first + jj;
         if (pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
             typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
             rng.init(P.seed_lo, P.seed_hi);
             rng.start_path(pixel, sample);
-            const uint32_t i_col = pixel % P.width;
-            const uint32_t i_row = pixel / P.width;
+            const uint32_t i_row = P.div_width.div(pixel);
+            const uint32_t i_col = pixel - i_row * P.width;
             float xi_u, xi_v;
             rng.next2(xi_u, xi_v);
             const float u = ((float)i_col + xi_u) / (float)P.width;
@@ -1455,6 +1489,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.tile_pixels = cfg->tile_pixels; P.tile_count = cfg->tile_count; P.tile_index = cfg->tile_index;
     P.direct = (nchunks == 1) ? 1u : 0u;
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
+    P.div_width = make_fastdiv(cfg->width); P.div_chunk = make_fastdiv(chunk); P.div_tile = make_fastdiv(cfg->tile_pixels ? cfg->tile_pixels : 1u);
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
     P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
@@ -1478,6 +1513,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     for (uint32_t slot0 = 0; slot0 < npix; slot0 += seg, ++nseg) {
         P.slot0 = slot0;
         P.npix = std::min(seg, npix - slot0);
+        P.div_npix = make_fastdiv(P.npix);
         if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
         if (primary) {
             const bool timed = nseg < kMaxTimedSegments;
