@@ -1445,19 +1445,33 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     const uint64_t part_per_slot = (nchunks > 1) ? (uint64_t)nchunks * 3u * sizeof(float) : 0u;
     const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListCap * sizeof(uint32_t);
     // the lists hold rays that leave the lens forwards; the no-allocation entry point keeps the camera rays in the megakernel
-    bool primary = !noalloc && cfg->t_min >= 0.0f && ctx->primary_cap != 0 && fit_slots(ctx->primary_cap - std::min<uint64_t>(ctx->primary_cap, 1024u), prim_per_slot) >= 64;
-    uint64_t fit = fit_slots(part_avail, part_per_slot);
-    if (fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
-    if (primary) fit = std::min(fit, fit_slots(ctx->primary_cap - 1024u, prim_per_slot));
-    uint64_t seg64 = npix;
-    if (fit < seg64) seg64 = fit / 64u * 64u;
-    {   // u32 item ids incl. the waves' last (overshooting) reservations; u32 record ids
+    uint64_t prim_cap = (noalloc || cfg->t_min < 0.0f) ? 0u : ctx->primary_cap;
+    const uint64_t part_fit = fit_slots(part_avail, part_per_slot);
+    if (part_fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
+    bool primary;
+    uint32_t seg;
+    size_t rec_bytes = 0;
+    for (;;) { // sized once, unless the device cannot give the primary pass its buffer: then with half of it, ..., then without the pass
+        primary = prim_cap > 1024u && fit_slots(prim_cap - 1024u, prim_per_slot) >= 64;
+        uint64_t fit = part_fit;
+        if (primary) fit = std::min(fit, fit_slots(prim_cap - 1024u, prim_per_slot));
+        uint64_t seg64 = npix;
+        if (fit < seg64) seg64 = fit / 64u * 64u;
+        // u32 item ids incl. the waves' last (overshooting) reservations; u32 record ids
         const uint64_t max_items = 0xf0000000ull;
         if (seg64 * nchunks > max_items) seg64 = max_items / nchunks / 64u * 64u;
         if (primary && seg64 * nchunks * chunk > max_items) seg64 = max_items / ((uint64_t)nchunks * chunk) / 64u * 64u;
         if (seg64 == 0) return PT_ERR_BAD_ARG;
+        seg = (uint32_t)seg64;
+        if (!primary) break;
+        rec_bytes = ((size_t)seg * nchunks * chunk * 32u + 255u) & ~(size_t)255u;
+        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, rec_bytes + (size_t)seg * kListCap * sizeof(uint32_t));
+        if (rc == PT_OK) rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
+        if (rc == PT_OK) break;
+        if (rc != PT_ERR_OOM) return rc;
+        (void)hipGetLastError();  // the failed allocation is not this render's error
+        prim_cap = std::min<uint64_t>(prim_cap, (uint64_t)seg * prim_per_slot) / 2u;
     }
-    const uint32_t seg = (uint32_t)seg64;
     if (nchunks > 1) {
         const size_t part_need = (size_t)seg * part_per_slot;
         if (noalloc) ws.part_bytes = part_need;
@@ -1466,14 +1480,6 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             if (rc != PT_OK) return rc;
             ws.part = ctx->d_part; ws.part_bytes = ctx->part_bytes;
         }
-    }
-    const size_t nrec_seg = (size_t)seg * nchunks * chunk;
-    const size_t rec_half = (nrec_seg * 16u + 255u) & ~(size_t)255u;
-    if (primary) {
-        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, 2u * rec_half + (size_t)seg * kListCap * sizeof(uint32_t));
-        if (rc != PT_OK) return rc;
-        rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
-        if (rc != PT_OK) return rc;
     }
 
     KParams P;
@@ -1497,7 +1503,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.stack = ws.stack; P.counters = ws.counters;
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
-    uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + 2u * rec_half) : nullptr;
+    uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + rec_bytes) : nullptr;
     P.lists = d_lists;
     const ListCam LC = primary ? make_list_cam(ctx->cam, cfg->width, cfg->height) : ListCam{};
     const bool one_seg = seg >= npix;

@@ -167,3 +167,38 @@ def test_negative_t_min_keeps_camera_rays_in_the_megakernel(orc, gpu):
     rc, ref, _ = orc.render_sum(scene.spheres, ocam, ocfg, nthreads=4)
     assert rc == 0
     np.testing.assert_array_equal(got, ref)
+
+
+def test_out_of_memory_falls_back_to_smaller_segments(gpu):
+    """When the device cannot give the primary pass the buffer its limit allows, the render takes half of it (and so on,
+    finally none) instead of failing: with all but ~6 GiB of the HBM held by someone else, a render whose records
+    need 10.6 GB still completes, in more segments, with the same bits."""
+    import torch
+    from path_tracer_amd import _lib, host
+    scene = host.Scene().setupScene(456, 21)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(host.Camera.preset(21).pod)
+    img = host.Image(1920)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=40, rebounds=50)      # 160 samples: 5 KiB of records per pixel
+    cfg = host.make_pt_config(img, rt, seed=5, chunk=16)
+    frame = torch.zeros(img.num_pixels * 3, dtype=torch.float32, device="cuda")
+    gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 2 << 30)
+    gpu.render_sum_device(cfg, frame.data_ptr())
+    torch.cuda.synchronize()
+    want = frame.clone()
+    hog = None
+    try:
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 1 << 40)
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(max(free - (6 << 30), 0), dtype=torch.uint8, device="cuda")
+        frame.zero_()
+        gpu.render_sum_device(cfg, frame.data_ptr())
+        torch.cuda.synchronize()
+        st = gpu.stats()
+        assert st.segments >= 2 and st.primary_rays == st.paths
+        assert torch.equal(frame, want)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
