@@ -68,7 +68,7 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 constexpr int kSub = PT_SUB;         // filter records held in registers ahead of their tests (software pipeline depth)
 static_assert(kPad % kSub == 0 && kMaskTile % 32 == 0 && kTile % kMaskTile == 0, "tile constants");
 constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of the filter
-// primary pass: candidate-list capacity per pixel and the record tags (bits 31:30 of rec_a.w)
+// primary pass: candidate-list capacity per pixel and the record tags (bits 31:30 of the first half's .w)
 constexpr uint32_t kListCap = 16;
 constexpr uint32_t kListEnd = 0xffffffffu, kListOverflow = 0xfffffffeu;
 constexpr uint32_t kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 2u, kTagState1 = 3u;
@@ -1450,7 +1450,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     if (part_fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
     bool primary;
     uint32_t seg;
-    size_t rec_bytes = 0;
+    size_t prim_rec_bytes = 0;
     for (;;) { // sized once, unless the device cannot give the primary pass its buffer: then with half of it, ..., then without the pass
         primary = prim_cap > 1024u && fit_slots(prim_cap - 1024u, prim_per_slot) >= 64;
         uint64_t fit = part_fit;
@@ -1464,8 +1464,8 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         if (seg64 == 0) return PT_ERR_BAD_ARG;
         seg = (uint32_t)seg64;
         if (!primary) break;
-        rec_bytes = ((size_t)seg * nchunks * chunk * 32u + 255u) & ~(size_t)255u;
-        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, rec_bytes + (size_t)seg * kListCap * sizeof(uint32_t));
+        prim_rec_bytes = ((size_t)seg * nchunks * chunk * 32u + 255u) & ~(size_t)255u;
+        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, prim_rec_bytes + (size_t)seg * kListCap * sizeof(uint32_t));
         if (rc == PT_OK) rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
         if (rc == PT_OK) break;
         if (rc != PT_ERR_OOM) return rc;
@@ -1503,7 +1503,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.stack = ws.stack; P.counters = ws.counters;
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
-    uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + rec_bytes) : nullptr;
+    uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
     P.lists = d_lists;
     const ListCam LC = primary ? make_list_cam(ctx->cam, cfg->width, cfg->height) : ListCam{};
     const bool one_seg = seg >= npix;
