@@ -21,7 +21,7 @@ def collect(kernel):
 
 
 vals, bench = collect("pt_megakernel")
-kms = bench["roofline"].get("megakernel_ms", bench["roofline"]["kernel_ms"])  # the megakernel's own time when the primary pass ran
+kms = bench["roofline"]["kernel_ms"]  # the megakernel's own time (roofline.kernel)
 lines = ["# %s — SQ counters of pt_megakernel (one launch: 1080p, 256 paths/pixel, depth 50)" % tag, "",
          "Collected by tools/collect_profile.sh in separate --pmc passes (no tracing).", "", "| counter | value |", "|---|---|"]
 for k in sorted(vals):
@@ -43,7 +43,7 @@ derived = {
 }
 rl = bench["roofline"]
 if "wave_steps_per_launch" in rl:
-    steps = rl["wave_steps_per_launch"]
+    steps = rl["wave_steps_per_launch"] * rl.get("launches", 1)
     per_step = vals["SQ_INSTS_VALU"] / steps
     scan = rl["shared_ordinate_tests"] * 7 + (rl["spheres"] - rl["shared_ordinate_tests"]) * 9
     derived["VALU wave-instructions per ray step (SQ_INSTS_VALU / wave steps of the launch)"] = per_step
@@ -60,11 +60,11 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
 lines += ["", "| derived | value |", "|---|---|"]
 for k, v in derived.items():
     lines.append("| %s | %.4g |" % (k, v))
-lines += ["", "megakernel ms of the counted launch: %.2f; algorithmic roofline fraction of that run (all tracing kernels): %.3f%s"
-          % (kms, bench["roofline"]["frac"], "; of the megakernel alone: %.3f" % rl["megakernel_frac"] if "megakernel_frac" in rl else "")]
+lines += ["", "megakernel ms of the counted launch: %.2f; its algorithmic roofline fraction in that run: %.3f; of the whole render (all tracing kernels, every ray priced as the reference's scan): %.3f"
+          % (kms, rl["frac"], rl["render"]["algorithmic_frac"])]
 pv, _ = collect("pt_primary<")
 if pv:
-    paths = rl.get("primary_rays_per_launch", 0.0)
+    paths = rl["render"]["primary_rays"]
     lines += ["", "## pt_primary (camera rays against their pixel's candidate list + first radiance step) in the same launch", "",
               "| counter | value |", "|---|---|"]
     for k in sorted(pv):
@@ -72,6 +72,6 @@ if pv:
     lines += ["", "| derived | value |", "|---|---|",
               "| VALU wave-instructions per 64 paths | %.4g |" % (pv["SQ_INSTS_VALU"] / max(paths / 64.0, 1.0)),
               "| VALUUtilization (active lanes per VALU instruction) | %.4g |" % (pv["SQ_THREAD_CYCLES_VALU"] / (pv["SQ_ACTIVE_INST_VALU"] * 64)),
-              "| primary pass ms (lists + pt_primary, HIP events) | %.4g |" % rl.get("primary_pass_ms", float("nan"))]
+              "| primary pass ms (lists + pt_primary, HIP events) | %.4g |" % rl["render"]["primary_pass_ms"]]
 open("profiles/%s_megakernel_counters.md" % tag, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
