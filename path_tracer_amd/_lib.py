@@ -26,6 +26,7 @@ PT_ERR_RCCL = -11
 
 PT_LIMIT_PARTIAL_BYTES = 0
 PT_LIMIT_PRIMARY_BYTES = 1
+PT_LIMIT_PRIMARY_BOUNCES = 2
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
@@ -68,7 +69,7 @@ class pt_stats(C.Structure):
                 ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("segments", C.c_uint64), ("primary_rays", C.c_uint64),
-                ("primary_ms", C.c_double)]
+                ("list2_rays", C.c_uint64), ("primary_ms", C.c_double)]
 
 
 assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104

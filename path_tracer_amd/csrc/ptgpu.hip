@@ -71,10 +71,20 @@ constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of 
 // primary pass: candidate-list capacity per pixel and the record tags (bits 31:30 of the first half's .w)
 constexpr uint32_t kListCap = 16;
 constexpr uint32_t kListEnd = 0xffffffffu, kListOverflow = 0xfffffffeu;
-constexpr uint32_t kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 2u, kTagState1 = 3u;
+// per pixel slot: [0,16) list A (camera rays); 16: sphere S of the second-bounce list (kListEnd: none), 17..19: p0, 20: patch radius^2
+// (f32 bits); [24,40) list B: spheres a ray scattered off S near p0 can hit
+#ifndef PT_LIST_CAP_B
+#define PT_LIST_CAP_B 16
+#endif
+constexpr uint32_t kListCapB = PT_LIST_CAP_B;
+constexpr uint32_t kListS = 16, kListP0 = 17, kListRho2 = 20, kListB = 24, kListStride = kListB + kListCapB;
+// record tags, bits 31:29 of the first half's .w (states have bit 31 set); bits 28:0 = first hit id
+constexpr uint32_t kTagShift = 29, kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 4u, kTagState1 = 5u, kTagState2 = 6u;
+constexpr uint32_t kHitMask = (1u << kTagShift) - 1u;
+constexpr uint32_t kDrawBits = 13;  // STATE2 packs (draws taken, second hit id) into the second half's .w: 13 + 19 bits
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
 // x / d for any u32 x without the ~35-instruction expansion of a run-time integer division: mulhi by a
 // host-computed magic number (the "branch-free" scheme: t = mulhi(x, M); q = (t + ((x - t) >> 1)) >> s).
@@ -132,7 +142,7 @@ struct KParams {
     uint32_t primary;       // 1: the records exist; the megakernel starts its paths from them instead of casting camera rays
     float4 *rec;            // record r = rec[2r], rec[2r+1]: (colour | origin, tag<<30 | first hit id), (direction, draws taken) — 32 B, so that
                             // the two halves share a cache line and a line holds a lane's next record too
-    const uint32_t *lists;  // [npix][kListCap]: candidate spheres of each pixel slot's camera rays (pt_primary_lists)
+    const uint32_t *lists;  // [npix][kListStride]: candidate spheres of each pixel slot's camera rays and of its second-bounce rays (pt_primary_lists)
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
 };
@@ -491,12 +501,14 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                     const uint32_t r = rec_base + sample;
                     const float4 ra = P.rec[2u * (size_t)r], rb = P.rec[2u * (size_t)r + 1u]; // both halves at once: one round trip
                     const uint32_t meta = __float_as_uint(ra.w);
-                    const uint32_t tag = meta >> 30;
+                    const uint32_t tag = meta >> kTagShift;
                     if (tag >= kTagState0) {
                         o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
-                        rng.resume(pixel, sample, __float_as_uint(rb.w));
-                        bounce = tag - kTagState0; // 0: camera ray, 1: after the first bounce
-                        if (bounce) P.stack[gtid] = meta & 0x3fffffffu; // stack[0][gtid]: the first hit's id
+                        bounce = tag - kTagState0; // 0: camera ray, 1 / 2: after the first / second bounce
+                        const uint32_t w = __float_as_uint(rb.w);
+                        rng.resume(pixel, sample, bounce == 2u ? (w & ((1u << kDrawBits) - 1u)) : w);
+                        if (bounce) P.stack[gtid] = meta & kHitMask;                                  // stack[0][gtid]: the first hit's id
+                        if (bounce == 2u) P.stack[(size_t)P.total_threads + gtid] = w >> kDrawBits;   // stack[1][gtid]
                         need_path = false;
                         break;
                     }
@@ -662,6 +674,9 @@ struct ListCam {
     double O[3], llc[3], H[3], V[3];
     double Rl, Rp, e_o, e_d;
 };
+#ifndef PT_PATCH_FACTOR
+#define PT_PATCH_FACTOR 1.05 // measured on the headline frame, 0.5 / 0.75 / 1.05 / 1.3 / 2 / 3: 60.1 / 57.1 / 56.8 / 57.5 / 58.2 / 59.5 ms per 256 samples; second-bounce lists: patch radius in units of the camera rays' footprint on the sphere (a choice: pt_primary checks each hit point)
+#endif
 constexpr double kListGamma = 4e-6; // >= 9x the rounding bound of the f32 discriminant: 2^-24 (14 |oc|^2 + 6 r^2) a
 
 __device__ __forceinline__ bool list_piece(double DD, double xx, double xd, double R, double beta, double ta, double tb) {
@@ -678,7 +693,7 @@ __device__ __forceinline__ bool list_piece(double DD, double xx, double xd, doub
 // |x| and r' for the quick reject.
 struct ListSphere {
     double x[3], xx, reff;
-    float xl, rub;
+    float xl, rub, r, pad_;
 };
 __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float4 *__restrict__ geom, uint32_t nspheres, ListSphere *__restrict__ out) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -693,16 +708,19 @@ __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float
     S.xl = sqrtf((float)S.xx) * (1.0f + 1e-6f);                  // >= |x|
     const float xr = S.xl + (float)C.Rl * (1.0f + 1e-6f);
     S.rub = (fabsf(g.w) + sqrtf((float)kListGamma * (2.0f * xr * xr + g.w * g.w))) * (1.0f + 1e-5f); // >= r'
+    S.r = g.w; S.pad_ = 0.f;
     out[j] = S;
 }
 
 __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_t width, uint32_t height, uint32_t slot0, uint32_t npix,
                                                         uint32_t idx_start, uint32_t idx_stop, uint32_t tile_pixels, uint32_t tile_count,
                                                         uint32_t tile_index, const ListSphere *__restrict__ sph, uint32_t nspheres,
+                                                        const uint32_t *__restrict__ kind, float t_min, uint32_t second_bounce,
                                                         uint32_t *__restrict__ lists) {
     const uint32_t po = blockIdx.x * 256u + threadIdx.x;
     if (po >= npix) return;
-    uint32_t *L = lists + (size_t)po * kListCap;
+    uint32_t *L = lists + (size_t)po * kListStride;
+    L[kListS] = kListEnd;
     const uint32_t pixel = slot_to_pixel(slot0 + po, idx_start, tile_pixels, tile_count, tile_index);
     if (pixel >= idx_stop) { L[0] = kListEnd; return; }
     const uint32_t col = pixel % width, row = pixel / width;
@@ -740,8 +758,106 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
             count++;
         }
     }
-    if (count > kListCap) L[0] = kListOverflow;  // too many: this pixel's camera rays take the scan
-    else if (count < kListCap) L[count] = kListEnd;
+    if (count > kListCap) { L[0] = kListOverflow; return; }  // too many: this pixel's camera rays take the scan
+    if (count < kListCap) L[count] = kListEnd;
+    if (!second_bounce || count == 0u) return;
+
+    // ---- list B: what a ray scattered off the pixel's main sphere can hit ---------------------------------
+    // S = the first hit of the pixel's CENTRAL ray, if Lambertian (material.zig:43-51: direction unit(n + rnd), rnd in
+    // [0,1)^3).  The list is built for rays that start within rho_p of the central hit point p0 on S — pt_primary
+    // checks that of each path's own hit point before it uses the list, so rho_p is a choice, not a bound — with
+    // n + rnd inside the box [n0 - eps, n0 + 1 + eps]^3 (eps: the turn of the normal over the patch + f32 rounding),
+    // i.e. inside the circular cone (axis a, half-angle alpha) around that box.  A sphere (c, r) such a ray hits has
+    // its centre within r' + rho_p of the cone with apex p0:  angle(c - p0, a) <= alpha + asin((r' + rho_p) / |c - p0|).
+    // Candidates for S: the Lambertian spheres of list A the central ray enters (near root beyond t_min), nearest first;
+    // the first one whose patch is flat enough for a cone wins (a small sphere in front of the ground is too curved under
+    // a wide lens: the ground behind it then gets the list, for the pixel's rays that pass the small one).
+    const double lenDv = sqrt(DD), tau_min = (double)t_min / lenDv;
+    double taus[kListCap];
+    uint32_t order[kListCap], ncand = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t j = L[i];
+        if (kind[j] != 0u) continue;
+        const ListSphere &S = sph[j];
+        const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
+        const double disc = xd * xd - DD * (S.xx - (double)S.r * (double)S.r);
+        if (disc < 0.0) continue;
+        const double tau = (xd - sqrt(disc)) * invDD; // near root only, as sphere.zig:75-86
+        if (!(tau > tau_min)) continue;
+        uint32_t k = ncand++;
+        while (k > 0 && taus[k - 1] > tau) { taus[k] = taus[k - 1]; order[k] = order[k - 1]; --k; }
+        taus[k] = tau; order[k] = j;
+    }
+    uint32_t Sj = kListEnd;
+    double tau0 = 0.0, p0[3], ax[3], rho_p = 0.0, cosA = 1.0, sinA = 0.0;
+    for (uint32_t ic = 0; ic < ncand && Sj == kListEnd; ++ic) {
+        const ListSphere &SS = sph[order[ic]];
+        tau0 = taus[ic];
+        double y0[3], n0[3], yl0 = 0.0, pl0 = 0.0, ndv = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            y0[i] = tau0 * Dv[i] - SS.x[i];          // p0 - c_S
+            p0[i] = C.O[i] + tau0 * Dv[i];
+            yl0 += y0[i] * y0[i]; pl0 += p0[i] * p0[i];
+        }
+        yl0 = sqrt(yl0); pl0 = sqrt(pl0);
+        if (!(yl0 > 0.0)) continue;
+        const double sgn = SS.r < 0.0f ? -1.0 : 1.0; // sphere.zig:88: (p - c) / radius, a negative radius turns the normal inwards
+        for (int i = 0; i < 3; ++i) { n0[i] = sgn * y0[i] / yl0; ndv += n0[i] * Dv[i]; }
+        const double cos_in = fabs(ndv) / lenDv;
+        const double rho0 = tau0 <= 1.0 ? a1 + b1 * tau0 : a2 + b2 * tau0;
+        rho_p = PT_PATCH_FACTOR * rho0 / fmax(cos_in, 0.05) + 2e-4 * (pl0 + 1.0);
+        const double eps_n = rho_p / fabs((double)SS.r) * 1.001;
+        if (!(eps_n <= 0.5)) continue;
+        const double eps = eps_n + 1e-5 * (pl0 + rho_p + 2.0);
+        double al = 0.0;
+        for (int i = 0; i < 3; ++i) { ax[i] = n0[i] + 0.5; al += ax[i] * ax[i]; } // box centre
+        al = sqrt(al);
+        if (!(al > 1e-3)) continue;
+        for (int i = 0; i < 3; ++i) ax[i] /= al;
+        cosA = 1.0;
+        bool ok = true;
+        for (int c = 0; c < 8; ++c) {
+            double u[3], ul = 0.0, au = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                u[i] = ((c >> i) & 1) ? n0[i] + 1.0 + eps : n0[i] - eps;
+                ul += u[i] * u[i]; au += ax[i] * u[i];
+            }
+            ul = sqrt(ul);
+            if (!(ul > 1e-6)) { ok = false; break; }
+            cosA = fmin(cosA, au / ul);
+        }
+        if (!ok || !(cosA >= 0.1)) continue;      // the box must lie well inside a half-space (it must not reach the origin)
+        sinA = sqrt(fmax(0.0, 1.0 - cosA * cosA));
+        Sj = order[ic];
+    }
+    if (Sj == kListEnd) return;
+    uint32_t *B = L + kListB;
+    uint32_t cnt2 = 0;
+    for (uint32_t j = 0; j < nspheres; ++j) {
+        const ListSphere &S = sph[j];
+        const double y_0 = S.x[0] - tau0 * Dv[0], y_1 = S.x[1] - tau0 * Dv[1], y_2 = S.x[2] - tau0 * Dv[2]; // c_j - p0
+        const double yy = y_0 * y_0 + y_1 * y_1 + y_2 * y_2;
+        const double yl = sqrt(yy);
+        const double r2 = (double)S.r * (double)S.r;
+        const double yr = yl + rho_p;
+        const double R = sqrt(r2 + kListGamma * (2.0 * yr * yr + r2)) + rho_p;
+        bool cand = yy <= R * R;
+        if (!cand) {
+            const double cosphi = (y_0 * ax[0] + y_1 * ax[1] + y_2 * ax[2]) / yl;
+            const double sinb = R / yl, cosb = sqrt(1.0 - sinb * sinb);
+            cand = cosphi >= cosA * cosb - sinA * sinb - 1e-9;
+        }
+        if (cand) {
+            if (cnt2 < kListCapB) B[cnt2] = j;
+            cnt2++;
+        }
+    }
+    if (cnt2 > kListCapB) return;
+    if (cnt2 < kListCapB) B[cnt2] = kListEnd;
+    L[kListP0] = __float_as_uint((float)p0[0]); L[kListP0 + 1] = __float_as_uint((float)p0[1]); L[kListP0 + 2] = __float_as_uint((float)p0[2]);
+    const double rc = 0.98 * rho_p;
+    L[kListRho2] = __float_as_uint((float)(rc * rc) * (1.0f - 1e-6f));
+    L[kListS] = Sj;
 }
 
 // One thread per path of the launch, in record order (item-major, the item's samples consecutive): the
@@ -751,7 +867,7 @@ template <bool DET>
 __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
     // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
-    uint32_t rays = 0, cands = 0, not_unit = 0;
+    uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
         const uint32_t item = P.div_chunk.div(r), jj = r - item * P.chunk;
         const uint32_t k = P.div_npix.div(item), po = item - k * P.npix;
@@ -771,69 +887,93 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             const V3 disk = random_vector_in_unit_disk(rng);
             V3 o, d;
             cast_ray_from_disk(P.cam, u, v, disk, o, d);
-            const uint32_t *L = P.lists + (size_t)po * kListCap;
+            const uint32_t *L = P.lists + (size_t)po * kListStride;
             // a disk draw kept after PT_MAX_TRIES failed tries may lie outside the lens the list was built for
 #ifdef PT_EXPERIMENT_TRIES1 // tools/build_variant.sh with -DPT_MAX_TRIES=1: what the rejection loops' retries cost this kernel (timing only, breaks parity)
             const bool listed = L[0] != kListOverflow;
 #else
             const bool listed = L[0] != kListOverflow && vlen2(disk) < 1.0f;
 #endif
-            float4 ra, rb;
-            if (!listed) {
-                ra = make_float4(o.x, o.y, o.z, __uint_as_float(kTagState0 << 30));
-                rb = make_float4(d.x, d.y, d.z, __uint_as_float(rng.drawn()));
-            } else {
-                const float a = vlen2(d); // sphere.zig:68
-                float closest = P.t_max;
-                int hit = -1;
-                for (uint32_t i = 0; i < kListCap; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
-                    const uint32_t j = L[i];
-                    if (j == kListEnd) break;
-                    const float4 g = P.geom[j];
-                    cands++;
-                    float t;
-                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
-                        if (t < closest) { closest = t; hit = (int)j; }
-                    }
-                }
-                rays++;
-                const float d_len = sqrtf(a);
-                V3 color = v3(0.f, 0.f, 0.f);
-                uint32_t tag = kTagFinal;
-                ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra;
-                if (hit >= 0) {
-                    if (P.illum != PT_ILLUM_RADIANCE) {
-                        if (P.illum == PT_ILLUM_NORMAL) { // illumination.zig:45-47; sic: about the constant centre (0,0,-1)
-                            const V3 p = vadd(o, vmul(d, closest));
-                            const V3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
-                            color = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
-                        } else {                          // illumination.zig:65-69
-                            const float4 m = P.mat[hit];
-                            color = (P.kind[hit] == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
+            // the record if nothing below gets further: the camera ray itself
+            float4 ra = make_float4(o.x, o.y, o.z, __uint_as_float(kTagState0 << kTagShift));
+            float4 rb = make_float4(d.x, d.y, d.z, __uint_as_float(rng.drawn()));
+            if (listed) {
+                uint32_t hit0 = 0;
+                // depth 0: the camera ray over list A; depth 1: the ray scattered off the pixel's main sphere over list B
+                for (uint32_t depth = 0;; ++depth) {
+                    const uint32_t *Ld = depth ? L + kListB : L;
+                    const float a = vlen2(d); // sphere.zig:68
+                    float closest = P.t_max;
+                    int hit = -1;
+                    const uint32_t cap = depth ? kListCapB : kListCap;
+                    for (uint32_t i = 0; i < cap; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
+                        const uint32_t j = Ld[i];
+                        if (j == kListEnd) break;
+                        const float4 g = P.geom[j];
+                        cands++;
+                        float t;
+                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
+                            if (t < closest) { closest = t; hit = (int)j; }
                         }
-                    } else if (P.rebounds != 0u) {        // rebounds == 0: illumination.zig:80-81, black
-                        const float4 g = P.geom[hit];
-                        const float4 m = P.mat[hit];
-                        V3 p, n;
-                        sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, P.inv_radius[hit], p, n);
-                        const V3 nd = scatter_pre(P.kind[hit], m.w, m.x, m.y, d_len, d, p, n, rng);
-                        tag = kTagState1;
-                        ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState1 << 30) | (uint32_t)hit));
-                        rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(rng.drawn()));
                     }
-                } else if (!lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color)) { // illumination.zig:88
-                    tag = kTagSkip;
-                    not_unit++;
+                    if (depth) rays2++; else rays++;
+                    const float d_len = sqrtf(a);
+                    V3 color = v3(0.f, 0.f, 0.f);
+                    uint32_t tag = kTagFinal;
+                    if (hit >= 0) {
+                        if (P.illum != PT_ILLUM_RADIANCE) {
+                            if (P.illum == PT_ILLUM_NORMAL) { // illumination.zig:45-47; sic: about the constant centre (0,0,-1)
+                                const V3 p = vadd(o, vmul(d, closest));
+                                const V3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
+                                color = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
+                            } else {                          // illumination.zig:65-69
+                                const float4 m = P.mat[hit];
+                                color = (P.kind[hit] == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
+                            }
+                        } else if (depth != P.rebounds) {     // depth == rebounds: illumination.zig:80-81, black
+                            const float4 g = P.geom[hit];
+                            const float4 m = P.mat[hit];
+                            const uint32_t kind = P.kind[hit];
+                            V3 p, n;
+                            sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, P.inv_radius[hit], p, n);
+                            const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                            const uint32_t drawn = rng.drawn();
+                            if (depth == 0u) {
+                                hit0 = (uint32_t)hit;
+                                ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState1 << kTagShift) | hit0));
+                                rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(drawn));
+                                // one more bounce here if this hit is the one list B was built for: the pixel's main sphere, within the patch
+                                const V3 dp = vsub(p, v3(__uint_as_float(L[kListP0]), __uint_as_float(L[kListP0 + 1]), __uint_as_float(L[kListP0 + 2])));
+                                if (hit0 == L[kListS] && vlen2(dp) <= __uint_as_float(L[kListRho2])) {
+                                    o = p; d = nd;
+                                    continue;
+                                }
+                            } else if (drawn < (1u << kDrawBits) && (uint32_t)hit < (1u << (32u - kDrawBits))) {
+                                ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState2 << kTagShift) | hit0));
+                                rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(drawn | ((uint32_t)hit << kDrawBits)));
+                            } else rays2--; // the record stays the one after the first bounce; the megakernel repeats (and counts) this step
+                            break;
+                        }
+                    } else if (!lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color)) { // illumination.zig:88
+                        tag = kTagSkip;
+                        not_unit++;
+                    } else if (depth) {
+                        // v.elementwiseMul(s.attenuation) of the first hit (illumination.zig:84-85)
+                        const float4 m = P.mat[hit0];
+                        color = (P.kind[hit0] != 2u) ? vemul(color, v3(m.x, m.y, m.z)) : vemul(color, v3(1.0f, 1.0f, 1.0f));
+                    }
+                    ra = make_float4(color.x, color.y, color.z, __uint_as_float(tag << kTagShift));
+                    break;
                 }
-                if (tag != kTagState1) ra = make_float4(color.x, color.y, color.z, __uint_as_float(tag << 30));
             }
             P.rec[2u * (size_t)r] = ra;
             if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
         }
     }
-    const unsigned long long w_rays = wave_sum_u64(rays), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
+    const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
     if ((threadIdx.x & 63u) == 0u) {
-        if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
+        if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays + w_rays2); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
+        if (w_rays2) atomicAdd(&P.counters[CNT_LIST2_RAYS], w_rays2);
         if (w_cands) atomicAdd(&P.counters[CNT_CANDS], w_cands);
         if (w_nu) atomicAdd(&P.counters[CNT_NOT_UNIT], w_nu);
     }
@@ -1079,6 +1219,7 @@ struct ptgpu_ctx {
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
     uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
     uint64_t primary_cap = 24ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
+    uint32_t primary_bounces = 2;                    // PT_LIMIT_PRIMARY_BOUNCES: 1 = camera rays only, 2 = also the rays scattered off each pixel's main sphere
     unsigned char *d_prim = nullptr; size_t prim_bytes = 0; // primary-pass records + candidate lists
     void *d_lsph = nullptr; size_t lsph_bytes = 0;          // ListSphere per sphere (pt_list_prep)
     std::vector<hipEvent_t> evp;                     // pairs around the primary pass of each segment (grown on demand)
@@ -1216,6 +1357,10 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
         return PT_OK;
     case PT_LIMIT_PRIMARY_BYTES:
         ctx->primary_cap = value;
+        return PT_OK;
+    case PT_LIMIT_PRIMARY_BOUNCES:
+        if (value < 1 || value > 2) return PT_ERR_BAD_ARG;
+        ctx->primary_bounces = (uint32_t)value;
         return PT_OK;
     default: return PT_ERR_BAD_ARG;
     }
@@ -1443,9 +1588,9 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     // the buffer of its records (32 B per path) and candidate lists
     auto fit_slots = [](uint64_t avail, uint64_t per_slot) -> uint64_t { return per_slot ? avail / per_slot : ~0ull; };
     const uint64_t part_per_slot = (nchunks > 1) ? (uint64_t)nchunks * 3u * sizeof(float) : 0u;
-    const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListCap * sizeof(uint32_t);
+    const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListStride * sizeof(uint32_t);
     // the lists hold rays that leave the lens forwards; the no-allocation entry point keeps the camera rays in the megakernel
-    uint64_t prim_cap = (noalloc || cfg->t_min < 0.0f) ? 0u : ctx->primary_cap;
+    uint64_t prim_cap = (noalloc || cfg->t_min < 0.0f || ctx->nspheres > kHitMask) ? 0u : ctx->primary_cap;
     const uint64_t part_fit = fit_slots(part_avail, part_per_slot);
     if (part_fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
     bool primary;
@@ -1465,7 +1610,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         seg = (uint32_t)seg64;
         if (!primary) break;
         prim_rec_bytes = ((size_t)seg * nchunks * chunk * 32u + 255u) & ~(size_t)255u;
-        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, prim_rec_bytes + (size_t)seg * kListCap * sizeof(uint32_t));
+        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, prim_rec_bytes + (size_t)seg * kListStride * sizeof(uint32_t));
         if (rc == PT_OK) rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
         if (rc == PT_OK) break;
         if (rc != PT_ERR_OOM) return rc;
@@ -1533,7 +1678,8 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             }
             hipLaunchKernelGGL(pt_primary_lists, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
                                cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
-                               ctx->nspheres, d_lists);
+                               ctx->nspheres, (const uint32_t *)ctx->d_kind, cfg->t_min,
+                               (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u, d_lists);
             HIP_TRY(ctx, hipGetLastError());
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
             const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);
@@ -1565,6 +1711,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     ctx->stats.sphere_tests = h[CNT_RAYS] * ctx->nspheres;
     ctx->stats.candidates = h[CNT_CANDS];
     ctx->stats.primary_rays = h[CNT_PRIMARY_RAYS];
+    ctx->stats.list2_rays = h[CNT_LIST2_RAYS];
     ctx->stats.primary_ms = 0.0;
     if (primary && nseg <= kMaxTimedSegments) {
         for (uint32_t i = 0; i < nseg; ++i) {

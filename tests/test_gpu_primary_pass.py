@@ -16,21 +16,30 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(gpu, cfg, expect_primary=True):
-    """render with the primary pass on and off; frames and counters must be identical"""
+    """render with the primary pass off, with camera rays only, and with the second bounce too; frames and counters must
+    be identical"""
     from path_tracer_amd import _lib
     try:
         gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, 2)
         on = gpu.render_sum(cfg, allow_not_unit=True)
         st_on = gpu.stats()
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, 1)
+        on1 = gpu.render_sum(cfg, allow_not_unit=True)
+        st_on1 = gpu.stats()
         gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 0)
         off = gpu.render_sum(cfg, allow_not_unit=True)
         st_off = gpu.stats()
     finally:
         gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
-    assert st_off.primary_rays == 0
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, 2)
+    assert st_off.primary_rays == 0 and st_off.list2_rays == 0 and st_on1.list2_rays == 0
+    assert st_on1.primary_rays == st_on.primary_rays
     if expect_primary:
         assert st_on.primary_rays > 0
-    assert (st_on.paths, st_on.rays, st_on.not_unit) == (st_off.paths, st_off.rays, st_off.not_unit)
+    for st in (st_on, st_on1):
+        assert (st.paths, st.rays, st.not_unit) == (st_off.paths, st_off.rays, st_off.not_unit)
+    np.testing.assert_array_equal(on1, off)
     np.testing.assert_array_equal(on, off)
     return on, st_on
 
@@ -48,6 +57,8 @@ def test_reference_scenes_on_off(gpu, n_scene, deterministic):
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=8, rebounds=50)
     _, st = _both(gpu, host.make_pt_config(img, rt, seed=3, chunk=5, deterministic=deterministic))
     assert st.primary_rays == st.paths            # every pixel of these frames has a list: no camera ray takes the scan
+    if not deterministic or n_scene == 21:
+        assert st.list2_rays > 0
 
 
 def test_ranges_tiles_samples_and_aovs_on_off(gpu):
@@ -112,7 +123,7 @@ def test_random_cameras_and_adversarial_scenes_on_off(gpu):
     rng = np.random.default_rng(11)
     img = host.Image(64)    # 64 x 36
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=16, t_min=0.001, t_max=1.0e6, rebounds=8)
-    listed = total = 0
+    listed = second = total = 0
     for trial in range(96):
         n = int(rng.choice([3, 40, 300, 700]))
         sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
@@ -131,8 +142,10 @@ def test_random_cameras_and_adversarial_scenes_on_off(gpu):
         gpu.set_camera(cam.pod)
         _, st = _both(gpu, host.make_pt_config(img, rt, seed=100 + trial, chunk=16), expect_primary=False)
         listed += st.primary_rays
+        second += st.list2_rays
         total += st.paths
     assert 0.5 * total < listed < total     # both kinds of pixel were exercised: listed ones and overflowing ones
+    assert second > 0.02 * total            # and second-bounce lists were used
 
 
 def test_many_tile_scene_on_off(gpu):

@@ -25,15 +25,18 @@ def main():
     if "PROBE_PRIMARY_BYTES" in os.environ:  # 0: camera rays inside the megakernel
         from path_tracer_amd import _lib
         g.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, int(float(os.environ["PROBE_PRIMARY_BYTES"])))
+    if "PROBE_PRIMARY_BOUNCES" in os.environ:
+        from path_tracer_amd import _lib
+        g.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, int(os.environ["PROBE_PRIMARY_BOUNCES"]))
     buf = torch.zeros(img.height * img.width * 3, dtype=torch.float32, device="cuda")
     for it in range(3):
         t = time.time(); g.render_sum_device(cfg, buf.data_ptr()); dt = time.time() - t
         st = g.stats()
         tests = st.rays * len(sp)
         flops = tests * 18 + st.rays * 60 + st.paths * 40
-        print("   lane util %.3f  flush iters/step %.2f  segments %d  primary: %.3e rays (%.1f%% of rays) %.1f ms" % (
-            (st.rays - st.primary_rays) / (64.0 * max(st.wave_steps, 1)), st.flush_iters / max(st.wave_steps, 1), st.segments, st.primary_rays,
-            100.0 * st.primary_rays / max(st.rays, 1), st.primary_ms))
+        print("   lane util %.3f  flush iters/step %.2f  segments %d  primary: %.3e + %.3e rays (%.1f%% of rays) %.1f ms" % (
+            (st.rays - st.primary_rays - st.list2_rays) / (64.0 * max(st.wave_steps, 1)), st.flush_iters / max(st.wave_steps, 1), st.segments, st.primary_rays,
+            st.list2_rays, 100.0 * (st.primary_rays + st.list2_rays) / max(st.rays, 1), st.primary_ms))
         print("iter %d: wall %.3fs kernel %.1f ms paths %.3e rays %.3e (%.2f rays/path) cands/ray %.2f | %.3e paths/s %.1f Mrays/s %.2f Gtests/s %.1f TFLOP/s (%.1f%% of 157.3)" % (
             it, dt, st.kernel_ms, st.paths, st.rays, st.rays / st.paths, st.candidates / st.rays,
             st.paths / (st.kernel_ms * 1e-3), st.rays / (st.kernel_ms * 1e-3) * 1e-6, tests / (st.kernel_ms * 1e-3) * 1e-9,
