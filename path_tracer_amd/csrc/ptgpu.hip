@@ -77,6 +77,7 @@ constexpr uint32_t kListEnd = 0xffffffffu, kListOverflow = 0xfffffffeu;
 #define PT_LIST_CAP_B 16
 #endif
 constexpr uint32_t kListCapB = PT_LIST_CAP_B;
+constexpr uint32_t kListTile = 256; // spheres per LDS tile of pt_primary_lists (72 B each)
 constexpr uint32_t kListS = 16, kListP0 = 17, kListRho2 = 20, kListB = 24, kListStride = kListB + kListCapB;
 // record tags, bits 31:29 of the first half's .w (states have bit 31 set); bits 28:0 = first hit id
 constexpr uint32_t kTagShift = 29, kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 4u, kTagState1 = 5u, kTagState2 = 6u;
@@ -693,7 +694,7 @@ __device__ __forceinline__ bool list_piece(double DD, double xx, double xd, doub
 // |x| and r' for the quick reject.
 struct ListSphere {
     double x[3], xx, reff;
-    float xl, rub, r, pad_;
+    float xl, rub, r, xf[3]; // xf = (float)x
 };
 __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float4 *__restrict__ geom, uint32_t nspheres, ListSphere *__restrict__ out) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -708,7 +709,8 @@ __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float
     S.xl = sqrtf((float)S.xx) * (1.0f + 1e-6f);                  // >= |x|
     const float xr = S.xl + (float)C.Rl * (1.0f + 1e-6f);
     S.rub = (fabsf(g.w) + sqrtf((float)kListGamma * (2.0f * xr * xr + g.w * g.w))) * (1.0f + 1e-5f); // >= r'
-    S.r = g.w; S.pad_ = 0.f;
+    S.r = g.w;
+    for (int i = 0; i < 3; ++i) S.xf[i] = (float)S.x[i];
     out[j] = S;
 }
 
@@ -717,12 +719,18 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
                                                         uint32_t tile_index, const ListSphere *__restrict__ sph, uint32_t nspheres,
                                                         const uint32_t *__restrict__ kind, float t_min, uint32_t second_bounce,
                                                         uint32_t *__restrict__ lists) {
+    // The per-sphere table goes through LDS in tiles (broadcast reads): read straight from memory the loops below were
+    // bound by the latency of one scalar load per sphere at three waves per SIMD.
+    __shared__ ListSphere s_sph[kListTile];
     const uint32_t po = blockIdx.x * 256u + threadIdx.x;
-    if (po >= npix) return;
-    uint32_t *L = lists + (size_t)po * kListStride;
-    L[kListS] = kListEnd;
-    const uint32_t pixel = slot_to_pixel(slot0 + po, idx_start, tile_pixels, tile_count, tile_index);
-    if (pixel >= idx_stop) { L[0] = kListEnd; return; }
+    bool act = po < npix;                      // this thread still builds list A
+    uint32_t *L = lists + (size_t)(act ? po : 0u) * kListStride;
+    uint32_t pixel = 0;
+    if (act) {
+        L[kListS] = kListEnd;
+        pixel = slot_to_pixel(slot0 + po, idx_start, tile_pixels, tile_count, tile_index);
+        if (pixel >= idx_stop) { L[0] = kListEnd; act = false; }
+    }
     const uint32_t col = pixel % width, row = pixel / width;
     // the (s, t) box of renderers/ppm_image.zig:61-62 (sic: +1 in v), centre
     const double sm = ((double)col + 0.5) / (double)width;
@@ -743,24 +751,34 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-5f) / lenD : 0.0f;
     const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f);
     uint32_t count = 0;
-    for (uint32_t j = 0; j < nspheres; ++j) {
-        const ListSphere &S = sph[j]; // wave-uniform address
-        const double xx = S.xx;
-        const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
-        if (lenD > 0.0f) {
-            const float base = S.rub + a1f;
-            const float tau_hi = (S.xl + base) * inv_lenD;
-            const float Rmax = (base + b2f * tau_hi) * (1.0f + 1e-5f);
-            if (xx - xd * xd * invDD > (double)Rmax * (double)Rmax) continue;
-        }
-        if (list_piece(DD, xx, xd, S.reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, S.reff + a2, b2, 1.0, 1e300)) {
-            if (count < kListCap) L[count] = j;
-            count++;
+    for (uint32_t t0 = 0; t0 < nspheres; t0 += kListTile) {
+        const uint32_t tn = min(kListTile, nspheres - t0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tn; i += 256u) s_sph[i] = sph[t0 + i];
+        __syncthreads();
+        if (!act) continue;
+#pragma unroll 4
+        for (uint32_t jj = 0; jj < tn; ++jj) {
+            const ListSphere &S = s_sph[jj]; // wave-uniform address
+            const double xx = S.xx;
+            const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
+            if (lenD > 0.0f) {
+                const float base = S.rub + a1f;
+                const float tau_hi = (S.xl + base) * inv_lenD;
+                const float Rmax = (base + b2f * tau_hi) * (1.0f + 1e-5f);
+                if (xx - xd * xd * invDD > (double)Rmax * (double)Rmax) continue;
+            }
+            if (list_piece(DD, xx, xd, S.reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, S.reff + a2, b2, 1.0, 1e300)) {
+                if (count < kListCap) L[count] = t0 + jj;
+                count++;
+            }
         }
     }
-    if (count > kListCap) { L[0] = kListOverflow; return; }  // too many: this pixel's camera rays take the scan
-    if (count < kListCap) L[count] = kListEnd;
-    if (!second_bounce || count == 0u) return;
+    if (act) {
+        if (count > kListCap) { L[0] = kListOverflow; act = false; }  // too many: this pixel's camera rays take the scan
+        else if (count < kListCap) L[count] = kListEnd;
+    }
+    bool doB = act && second_bounce && count != 0u; // this thread builds list B
 
     // ---- list B: what a ray scattered off the pixel's main sphere can hit ---------------------------------
     // S = the first hit of the pixel's CENTRAL ray, if Lambertian (material.zig:43-51: direction unit(n + rnd), rnd in
@@ -773,9 +791,10 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     // the first one whose patch is flat enough for a cone wins (a small sphere in front of the ground is too curved under
     // a wide lens: the ground behind it then gets the list, for the pixel's rays that pass the small one).
     const double lenDv = sqrt(DD), tau_min = (double)t_min / lenDv;
-    double taus[kListCap];
-    uint32_t order[kListCap], ncand = 0;
-    for (uint32_t i = 0; i < count; ++i) {
+    constexpr uint32_t kNear = 4;   // the nearest few are enough: S is almost always the first or the second of them
+    double taus[kNear];
+    uint32_t order[kNear], ncand = 0;
+    for (uint32_t i = 0; doB && i < count; ++i) {
         const uint32_t j = L[i];
         if (kind[j] != 0u) continue;
         const ListSphere &S = sph[j];
@@ -784,9 +803,18 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         if (disc < 0.0) continue;
         const double tau = (xd - sqrt(disc)) * invDD; // near root only, as sphere.zig:75-86
         if (!(tau > tau_min)) continue;
-        uint32_t k = ncand++;
-        while (k > 0 && taus[k - 1] > tau) { taus[k] = taus[k - 1]; order[k] = order[k - 1]; --k; }
-        taus[k] = tau; order[k] = j;
+        // insert into the kNear nearest, ascending (fixed-size, fully unrolled: the arrays stay in registers)
+        double tk = tau; uint32_t jk = j;
+#pragma unroll
+        for (uint32_t k = 0; k < kNear; ++k) {
+            const bool empty = k >= ncand;
+            if (empty || tk < taus[k]) {
+                const double tt = empty ? tk : taus[k]; const uint32_t jt = empty ? jk : order[k];
+                taus[k] = tk; order[k] = jk; tk = tt; jk = jt;
+                if (empty) break;
+            }
+        }
+        if (ncand < kNear) ncand++;
     }
     uint32_t Sj = kListEnd;
     double tau0 = 0.0, p0[3], ax[3], rho_p = 0.0, cosA = 1.0, sinA = 0.0;
@@ -830,29 +858,43 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         sinA = sqrt(fmax(0.0, 1.0 - cosA * cosA));
         Sj = order[ic];
     }
-    if (Sj == kListEnd) return;
+    doB = doB && Sj != kListEnd;
+    if (!__syncthreads_or(doB ? 1 : 0)) return;   // nobody in this workgroup: skip the second pass over the spheres
     uint32_t *B = L + kListB;
     uint32_t cnt2 = 0;
-    for (uint32_t j = 0; j < nspheres; ++j) {
-        const ListSphere &S = sph[j];
-        const double y_0 = S.x[0] - tau0 * Dv[0], y_1 = S.x[1] - tau0 * Dv[1], y_2 = S.x[2] - tau0 * Dv[2]; // c_j - p0
-        const double yy = y_0 * y_0 + y_1 * y_1 + y_2 * y_2;
-        const double yl = sqrt(yy);
-        const double r2 = (double)S.r * (double)S.r;
-        const double yr = yl + rho_p;
-        const double R = sqrt(r2 + kListGamma * (2.0 * yr * yr + r2)) + rho_p;
-        bool cand = yy <= R * R;
-        if (!cand) {
-            const double cosphi = (y_0 * ax[0] + y_1 * ax[1] + y_2 * ax[2]) / yl;
-            const double sinb = R / yl, cosb = sqrt(1.0 - sinb * sinb);
-            cand = cosphi >= cosA * cosb - sinA * sinb - 1e-9;
-        }
-        if (cand) {
-            if (cnt2 < kListCapB) B[cnt2] = j;
+    // The condition, (y.a) >= cosA sqrt(|y|^2 - R^2) - sinA R with y = c_j - p0 and R = r' + rho_p, is evaluated in f32
+    // with every bound taken on the permissive side (relative margins of 1e-5 against rounding of 1e-7: the lists grow by
+    // nothing measurable); v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf this file is compiled with.
+    float tdf[3], axf[3], tdl = 0.f;
+    for (int i = 0; i < 3; ++i) { tdf[i] = (float)(tau0 * Dv[i]); axf[i] = (float)ax[i]; tdl += tdf[i] * tdf[i]; }
+    tdl = __builtin_amdgcn_sqrtf(tdl) * (1.0f + 1e-6f);
+    const float cosAf = (float)cosA * (1.0f - 1e-5f) - 1e-5f, sinAf = (float)sinA * (1.0f + 1e-5f) + 1e-5f;
+    const float rho_pf = (float)rho_p * (1.0f + 1e-6f), gammaf = (float)kListGamma * (1.0f + 1e-6f);
+    for (uint32_t t0 = 0; t0 < nspheres; t0 += kListTile) {
+        const uint32_t tn = min(kListTile, nspheres - t0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tn; i += 256u) s_sph[i] = sph[t0 + i];
+        __syncthreads();
+        if (!doB) continue;
+#pragma unroll 4
+        for (uint32_t jj = 0; jj < tn; ++jj) {
+            const ListSphere &S = s_sph[jj];
+            const float yf0 = S.xf[0] - tdf[0], yf1 = S.xf[1] - tdf[1], yf2 = S.xf[2] - tdf[2];
+            const float err = 1e-6f * (S.xl + tdl);              // >= the error of yf (inputs rounded to f32, three subtractions)
+            const float yl = __builtin_amdgcn_sqrtf(yf0 * yf0 + yf1 * yf1 + yf2 * yf2);
+            const float ylu = yl * (1.0f + 1e-6f) + err + rho_pf;
+            const float Rf = (fabsf(S.r) + __builtin_amdgcn_sqrtf(gammaf * (2.0f * ylu * ylu + S.r * S.r)) + rho_pf) * (1.0f + 1e-5f) + err;
+            if (yl > Rf) {
+                const float ya = yf0 * axf[0] + yf1 * axf[1] + yf2 * axf[2] + err + 1e-6f * yl;
+                const float yll = fmaxf(yl * (1.0f - 1e-6f) - err, 0.0f);
+                const float rhs = cosAf * __builtin_amdgcn_sqrtf(fmaxf(yll * yll - Rf * Rf, 0.0f)) * (1.0f - 1e-5f) - sinAf * Rf;
+                if (ya < rhs - 1e-5f * (yl + Rf)) continue;
+            }
+            if (cnt2 < kListCapB) B[cnt2] = t0 + jj;
             cnt2++;
         }
     }
-    if (cnt2 > kListCapB) return;
+    if (!doB || cnt2 > kListCapB) return;
     if (cnt2 < kListCapB) B[cnt2] = kListEnd;
     L[kListP0] = __float_as_uint((float)p0[0]); L[kListP0 + 1] = __float_as_uint((float)p0[1]); L[kListP0 + 2] = __float_as_uint((float)p0[2]);
     const double rc = 0.98 * rho_p;
