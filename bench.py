@@ -145,7 +145,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, segments = [], [], 0, 0, 0, 0, 0
+    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, list2_rays, segments = [], [], 0, 0, 0, 0, 0, 0
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st.kernel_ms)   # HIP events around the tracing kernels (primary pass + megakernel), on the stream they ran on
@@ -153,7 +153,8 @@ def main():
         paths += st.paths
         rays += st.rays
         wave_steps += st.wave_steps
-        primary_rays += st.primary_rays
+        primary_rays += st.primary_rays + st.list2_rays   # every ray the primary pass resolved against a per-pixel list
+        list2_rays += st.list2_rays
         segments = st.segments
     fence()
     dt = time.perf_counter() - t0
@@ -180,7 +181,8 @@ def main():
         render_flops = algorithmic_flops(paths_l, rays_l, nsph)        # the reference's scan for EVERY ray of the render
         render = {"kernels": "pt_primary_lists + pt_primary + pt_megakernel" if prim_l else "pt_megakernel",
                   "kernel_ms": k_ms, "primary_pass_ms": p_ms, "segments": segments,
-                  "paths": paths_l, "rays": rays_l, "primary_rays": prim_l, "algorithmic_flops": render_flops,
+                  "paths": paths_l, "rays": rays_l, "primary_rays": prim_l, "of_which_second_bounce": list2_rays / args.steps,
+                  "algorithmic_flops": render_flops,
                   "algorithmic_frac": render_flops / (k_ms * 1e-3) / PEAK_FP32_VALU,
                   "executed_frac": executed_flops(paths_l, rays_l, nsph, shared, prim_l) / (k_ms * 1e-3) / PEAK_FP32_VALU}
         # the dominant kernel: the megakernel over the rays IT scans (every ray when the primary pass is off)
@@ -220,9 +222,9 @@ def main():
                                  "for the device-counted rays the megakernel traces, over its HIP-event time in rank 0's render (`launches` "
                                  "segment launches; rocprofv3's average duration x launches agrees): an algorithmic-work rate, not hardware "
                                  "utilisation.  `executed_frac` prices what its filter scan executes per test (7 FMA + 1 compare = 15 FLOP; "
-                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words).  Camera rays (`render.primary_rays`) "
-                                 "never reach the megakernel: the primary pass resolves them against their pixel's candidate list (same "
-                                 "closest hit, bit for bit).  `render` prices the WHOLE render the same way — the reference's scan for "
+                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words).  `render.primary_rays` rays — the camera rays and "
+                                 "(`of_which_second_bounce`) the rays scattered off each pixel's main diffuse sphere — never reach the "
+                                 "megakernel: the primary pass resolves them against per-pixel candidate lists (same closest hit, bit for bit).  `render` prices the WHOLE render the same way — the reference's scan for "
                                  "every ray over the time of all tracing kernels — which is why its algorithmic_frac can pass 1.  "
                                  "Issue-slot utilisation from the SQ counters is in profiles/"},
         }

@@ -143,6 +143,9 @@ struct KParams {
     uint32_t primary;       // 1: the records exist; the megakernel starts its paths from them instead of casting camera rays
     float4 *rec;            // record r = rec[2r], rec[2r+1]: (colour | origin, tag<<30 | first hit id), (direction, draws taken) — 32 B, so that
                             // the two halves share a cache line and a line holds a lane's next record too
+    uint32_t *item_mask;    // per item: bit j set = its sample j needs a look at its record (a state, or a dropped sample); clear = a finished
+                            // colour.  use_mask = 0 (chunk does not divide 64, or > 32): not written, every record is looked at
+    uint32_t use_mask;
     const uint32_t *lists;  // [npix][kListStride]: candidate spheres of each pixel slot's camera rays and of its second-bounce rays (pt_primary_lists)
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     bool need_path = true;  // lane needs a new camera sample
     uint32_t pixel = 0, sample = 0, s_end = 0, out_slot = 0;
     uint32_t rec_base = 0;  // primary pass: record of (item, sample) = rec_base + sample
+    uint32_t hmask = 0;     // primary pass: the item's mask, shifted so that bit 0 is the next sample to start
     bool has_item = false;
     V3 accum = v3(0.f, 0.f, 0.f);
     V3 o = v3(0.f, 0.f, 0.f), d = v3(kNaN, kNaN, kNaN); // parked (see phase A) until the first path starts
@@ -477,7 +481,10 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                         const uint32_t po = item - k * P.npix;
                         pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
                         sample = P.s0 + k * P.chunk;
-                        if (PRIMARY) rec_base = item * P.chunk - sample;
+                        if (PRIMARY) {
+                            rec_base = item * P.chunk - sample;
+                            hmask = P.use_mask ? P.item_mask[item] : 0xffffffffu;
+                        }
                         s_end = min(sample + P.chunk, P.s1);
                         out_slot = P.direct ? pixel : item; // frame[pixel] or part[k][po]
                         accum = v3(0.f, 0.f, 0.f);
@@ -497,24 +504,47 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             // and shaded the first hit (pt_primary).  A record is the path's colour (it ended there: added
             // here, in sample order), or the ray after the first bounce, or — pixels without a list — the
             // camera ray itself.
+            // The item's mask tells which of its samples ended in the primary pass: their colours (up to four at a
+            // time) and the record after them are fetched together — independent loads, one round trip — instead of
+            // walking the records one dependent load after the other.
             if (alive && need_path && sample != s_end) {
                 for (;;) {
-                    const uint32_t r = rec_base + sample;
-                    const float4 ra = P.rec[2u * (size_t)r], rb = P.rec[2u * (size_t)r + 1u]; // both halves at once: one round trip
-                    const uint32_t meta = __float_as_uint(ra.w);
-                    const uint32_t tag = meta >> kTagShift;
-                    if (tag >= kTagState0) {
-                        o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
-                        bounce = tag - kTagState0; // 0: camera ray, 1 / 2: after the first / second bounce
-                        const uint32_t w = __float_as_uint(rb.w);
-                        rng.resume(pixel, sample, bounce == 2u ? (w & ((1u << kDrawBits) - 1u)) : w);
-                        if (bounce) P.stack[gtid] = meta & kHitMask;                                  // stack[0][gtid]: the first hit's id
-                        if (bounce == 2u) P.stack[(size_t)P.total_threads + gtid] = w >> kDrawBits;   // stack[1][gtid]
-                        need_path = false;
-                        break;
+                    if (!P.use_mask) hmask = 0xffffffffu;
+                    const uint32_t left = s_end - sample;
+                    const uint32_t f = min(hmask ? (uint32_t)__builtin_ctz(hmask) : 32u, left); // finished samples in front
+                    const uint32_t fb = min(f, 4u);
+                    const bool look = fb == f && f < left;       // the record right behind this batch needs a look
+                    const size_t r = 2u * (size_t)(rec_base + sample);
+                    float4 c0, c1, c2, c3, ra, rb;
+                    c0 = c1 = c2 = c3 = ra = rb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (fb > 0u) c0 = P.rec[r];
+                    if (fb > 1u) c1 = P.rec[r + 2u];
+                    if (fb > 2u) c2 = P.rec[r + 4u];
+                    if (fb > 3u) c3 = P.rec[r + 6u];
+                    if (look) { ra = P.rec[r + 2u * f]; rb = P.rec[r + 2u * f + 1u]; }
+                    if (fb > 0u) accum = vadd(accum, v3(c0.x, c0.y, c0.z)); // renderers/ppm_image.zig:67, in sample order
+                    if (fb > 1u) accum = vadd(accum, v3(c1.x, c1.y, c1.z));
+                    if (fb > 2u) accum = vadd(accum, v3(c2.x, c2.y, c2.z));
+                    if (fb > 3u) accum = vadd(accum, v3(c3.x, c3.y, c3.z));
+                    sample += fb;
+                    hmask >>= fb;
+                    if (look) {
+                        const uint32_t meta = __float_as_uint(ra.w);
+                        const uint32_t tag = meta >> kTagShift;
+                        hmask >>= 1;
+                        if (tag >= kTagState0) {
+                            o = v3(ra.x, ra.y, ra.z); d = v3(rb.x, rb.y, rb.z);
+                            bounce = tag - kTagState0; // 0: camera ray, 1 / 2: after the first / second bounce
+                            const uint32_t w = __float_as_uint(rb.w);
+                            rng.resume(pixel, sample, bounce == 2u ? (w & ((1u << kDrawBits) - 1u)) : w);
+                            if (bounce) P.stack[gtid] = meta & kHitMask;                                  // stack[0][gtid]: the first hit's id
+                            if (bounce == 2u) P.stack[(size_t)P.total_threads + gtid] = w >> kDrawBits;   // stack[1][gtid]
+                            need_path = false;
+                            break;
+                        }
+                        if (tag == kTagFinal) accum = vadd(accum, v3(ra.x, ra.y, ra.z)); // (no mask: every record comes this way)
+                        sample++;                    // kTagSkip: DirectionIsNotUnitVector, counted by the primary pass
                     }
-                    if (tag == kTagFinal) accum = vadd(accum, v3(ra.x, ra.y, ra.z)); // renderers/ppm_image.zig:67
-                    sample++;                    // kTagSkip: DirectionIsNotUnitVector, counted by the primary pass
                     if (sample == s_end) {       // item finished without a ray to trace: ask for the next one, or park
                         o = v3(0.f, 0.f, 0.f); d = v3(kNaN, kNaN, kNaN);
                         break;
@@ -916,6 +946,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
         const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
         const uint32_t first = P.s0 + k * P.chunk;
         const uint32_t sample = first + jj;
+        bool look = false; // the megakernel has to look at this path's record (a state to continue, or a dropped sample)
         if (pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
             typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
             rng.init(P.seed_lo, P.seed_hi);
@@ -1010,6 +1041,11 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             }
             P.rec[2u * (size_t)r] = ra;
             if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
+            look = (__float_as_uint(ra.w) >> kTagShift) != kTagFinal;
+        }
+        if (P.use_mask) { // 64 % chunk == 0: an item's samples sit in one wave, lanes [lane - jj, lane - jj + chunk)
+            const unsigned long long m = __ballot(look);
+            if (jj == 0u) P.item_mask[item] = (uint32_t)(m >> (threadIdx.x & 63u)) & (uint32_t)((1ull << P.chunk) - 1ull);
         }
     }
     const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
@@ -1630,7 +1666,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     // the buffer of its records (32 B per path) and candidate lists
     auto fit_slots = [](uint64_t avail, uint64_t per_slot) -> uint64_t { return per_slot ? avail / per_slot : ~0ull; };
     const uint64_t part_per_slot = (nchunks > 1) ? (uint64_t)nchunks * 3u * sizeof(float) : 0u;
-    const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListStride * sizeof(uint32_t);
+    const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListStride * sizeof(uint32_t) + (uint64_t)nchunks * sizeof(uint32_t);
     // the lists hold rays that leave the lens forwards; the no-allocation entry point keeps the camera rays in the megakernel
     uint64_t prim_cap = (noalloc || cfg->t_min < 0.0f || ctx->nspheres > kHitMask) ? 0u : ctx->primary_cap;
     const uint64_t part_fit = fit_slots(part_avail, part_per_slot);
@@ -1652,7 +1688,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         seg = (uint32_t)seg64;
         if (!primary) break;
         prim_rec_bytes = ((size_t)seg * nchunks * chunk * 32u + 255u) & ~(size_t)255u;
-        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, prim_rec_bytes + (size_t)seg * kListStride * sizeof(uint32_t));
+        rc = ensure(ctx, (void **)&ctx->d_prim, &ctx->prim_bytes, prim_rec_bytes + (size_t)seg * kListStride * sizeof(uint32_t) + (size_t)seg * nchunks * sizeof(uint32_t));
         if (rc == PT_OK) rc = ensure(ctx, (void **)&ctx->d_lsph, &ctx->lsph_bytes, (size_t)ctx->nspheres * sizeof(ListSphere));
         if (rc == PT_OK) break;
         if (rc != PT_ERR_OOM) return rc;
@@ -1692,6 +1728,8 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
     P.lists = d_lists;
+    P.item_mask = primary ? d_lists + (size_t)seg * kListStride : nullptr;
+    P.use_mask = (primary && chunk <= 32u && 64u % chunk == 0u) ? 1u : 0u;
     const ListCam LC = primary ? make_list_cam(ctx->cam, cfg->width, cfg->height) : ListCam{};
     const bool one_seg = seg >= npix;
 
