@@ -64,7 +64,7 @@ lines += ["", "megakernel ms of the counted launch: %.2f; its algorithmic roofli
           % (kms, rl["frac"], rl["render"]["algorithmic_frac"])]
 pv, _ = collect("pt_primary<")
 if pv:
-    paths = rl["render"]["primary_rays"]
+    paths = rl["render"]["paths"]
     lines += ["", "## pt_primary (camera rays against their pixel's candidate list + first radiance step) in the same launch", "",
               "| counter | value |", "|---|---|"]
     for k in sorted(pv):

@@ -91,6 +91,7 @@ pub extern fn ptgpu_noalloc_scratch_bytes() u64;
 // device-memory limits of a context (INTEGRATION.md 4c); PT_LIMIT_PRIMARY_BYTES = 0 switches the primary pass off
 pub const PT_LIMIT_PARTIAL_BYTES: c_int = 0;
 pub const PT_LIMIT_PRIMARY_BYTES: c_int = 1;
+pub const PT_LIMIT_PRIMARY_BOUNCES: c_int = 2; // 1: camera rays only, 2 (default): also the rays scattered off each pixel's main diffuse sphere
 pub extern fn ptgpu_set_limit(ctx: *PtCtx, which: c_int, value: u64) c_int;
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
 pub extern fn ptgpu_abi_version() u32;
