@@ -71,14 +71,15 @@ constexpr float kKeps = 1.52587890625e-05f; // 2^-16: relative safety margin of 
 // primary pass: candidate-list capacity per pixel and the record tags (bits 31:30 of the first half's .w)
 constexpr uint32_t kListCap = 16;
 constexpr uint32_t kListEnd = 0xffffffffu, kListOverflow = 0xfffffffeu;
-// per pixel slot: [0,16) list A (camera rays); 16: sphere S of the second-bounce list (kListEnd: none), 17..19: p0, 20: patch radius^2
-// (f32 bits); [24,40) list B: spheres a ray scattered off S near p0 can hit
+// per pixel slot: [0,16) list A (camera rays); 16: sphere S of the second-bounce list (kListEnd: none), 17..19: p0, 20: patch radius^2,
+// 21..23: cone axis, 24: cosine of the cone's half-angle (f32 bits); [28,44) list B: spheres a ray can hit that starts in the patch
+// on S and runs inside the cone
 #ifndef PT_LIST_CAP_B
 #define PT_LIST_CAP_B 16
 #endif
 constexpr uint32_t kListCapB = PT_LIST_CAP_B;
 constexpr uint32_t kListTile = 256; // spheres per LDS tile of pt_primary_lists (72 B each)
-constexpr uint32_t kListS = 16, kListP0 = 17, kListRho2 = 20, kListB = 24, kListStride = kListB + kListCapB;
+constexpr uint32_t kListS = 16, kListP0 = 17, kListRho2 = 20, kListAxis = 21, kListCos = 24, kListB = 28, kListStride = kListB + kListCapB;
 // record tags, bits 31:29 of the first half's .w (states have bit 31 set); bits 28:0 = first hit id
 constexpr uint32_t kTagShift = 29, kTagFinal = 0u, kTagSkip = 1u, kTagState0 = 4u, kTagState1 = 5u, kTagState2 = 6u;
 constexpr uint32_t kHitMask = (1u << kTagShift) - 1u;
@@ -747,8 +748,8 @@ __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float
 __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_t width, uint32_t height, uint32_t slot0, uint32_t npix,
                                                         uint32_t idx_start, uint32_t idx_stop, uint32_t tile_pixels, uint32_t tile_count,
                                                         uint32_t tile_index, const ListSphere *__restrict__ sph, uint32_t nspheres,
-                                                        const uint32_t *__restrict__ kind, float t_min, uint32_t second_bounce,
-                                                        uint32_t *__restrict__ lists) {
+                                                        const uint32_t *__restrict__ kind, const float4 *__restrict__ mat, float t_min,
+                                                        uint32_t second_bounce, uint32_t *__restrict__ lists) {
     // The per-sphere table goes through LDS in tiles (broadcast reads): read straight from memory the loops below were
     // bound by the latency of one scalar load per sphere at three waves per SIMD.
     __shared__ ListSphere s_sph[kListTile];
@@ -811,13 +812,14 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     bool doB = act && second_bounce && count != 0u; // this thread builds list B
 
     // ---- list B: what a ray scattered off the pixel's main sphere can hit ---------------------------------
-    // S = the first hit of the pixel's CENTRAL ray, if Lambertian (material.zig:43-51: direction unit(n + rnd), rnd in
-    // [0,1)^3).  The list is built for rays that start within rho_p of the central hit point p0 on S — pt_primary
-    // checks that of each path's own hit point before it uses the list, so rho_p is a choice, not a bound — with
+    // S = a Lambertian or Metal sphere the pixel's CENTRAL ray hits (material.zig:43-51: direction unit(n + rnd), rnd in
+    // [0,1)^3; material.zig:79-88: unit(reflect(d, n) + fuzz rnd)).  The list is built for rays that start within rho_p of the central hit point p0 on S and run
+    // inside a cone (axis a, half-angle alpha) — pt_primary checks both of each path's own hit point and direction before it
+    // uses the list, so patch and cone are choices, not bounds; they are chosen to hold nearly all of the pixel's rays: with
     // n + rnd inside the box [n0 - eps, n0 + 1 + eps]^3 (eps: the turn of the normal over the patch + f32 rounding),
     // i.e. inside the circular cone (axis a, half-angle alpha) around that box.  A sphere (c, r) such a ray hits has
     // its centre within r' + rho_p of the cone with apex p0:  angle(c - p0, a) <= alpha + asin((r' + rho_p) / |c - p0|).
-    // Candidates for S: the Lambertian spheres of list A the central ray enters (near root beyond t_min), nearest first;
+    // Candidates for S: the Lambertian and Metal spheres of list A the central ray enters (near root beyond t_min), nearest first;
     // the first one whose patch is flat enough for a cone wins (a small sphere in front of the ground is too curved under
     // a wide lens: the ground behind it then gets the list, for the pixel's rays that pass the small one).
     const double lenDv = sqrt(DD), tau_min = (double)t_min / lenDv;
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     uint32_t order[kNear], ncand = 0;
     for (uint32_t i = 0; doB && i < count; ++i) {
         const uint32_t j = L[i];
-        if (kind[j] != 0u) continue;
+        if (kind[j] > 1u) continue;   // Lambertian or Metal: their scattered rays fill a cone (below)
         const ListSphere &S = sph[j];
         const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
         const double disc = xd * xd - DD * (S.xx - (double)S.r * (double)S.r);
@@ -867,25 +869,49 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         const double eps_n = rho_p / fabs((double)SS.r) * 1.001;
         if (!(eps_n <= 0.5)) continue;
         const double eps = eps_n + 1e-5 * (pl0 + rho_p + 2.0);
-        double al = 0.0;
-        for (int i = 0; i < 3; ++i) { ax[i] = n0[i] + 0.5; al += ax[i] * ax[i]; } // box centre
-        al = sqrt(al);
-        if (!(al > 1e-3)) continue;
-        for (int i = 0; i < 3; ++i) ax[i] /= al;
-        cosA = 1.0;
-        bool ok = true;
-        for (int c = 0; c < 8; ++c) {
-            double u[3], ul = 0.0, au = 0.0;
-            for (int i = 0; i < 3; ++i) {
-                u[i] = ((c >> i) & 1) ? n0[i] + 1.0 + eps : n0[i] - eps;
-                ul += u[i] * u[i]; au += ax[i] * u[i];
+        if (kind[order[ic]] == 0u) {
+            // Lambertian (material.zig:43-51): unit(n + rnd), rnd in [0,1)^3 — the box [n0 - eps, n0 + 1 + eps]^3
+            double al = 0.0;
+            for (int i = 0; i < 3; ++i) { ax[i] = n0[i] + 0.5; al += ax[i] * ax[i]; } // box centre
+            al = sqrt(al);
+            if (!(al > 1e-3)) continue;
+            for (int i = 0; i < 3; ++i) ax[i] /= al;
+            cosA = 1.0;
+            bool ok = true;
+            for (int c = 0; c < 8; ++c) {
+                double u[3], ul = 0.0, au = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    u[i] = ((c >> i) & 1) ? n0[i] + 1.0 + eps : n0[i] - eps;
+                    ul += u[i] * u[i]; au += ax[i] * u[i];
+                }
+                ul = sqrt(ul);
+                if (!(ul > 1e-6)) { ok = false; break; }
+                cosA = fmin(cosA, au / ul);
             }
-            ul = sqrt(ul);
-            if (!(ul > 1e-6)) { ok = false; break; }
-            cosA = fmin(cosA, au / ul);
+            if (!ok || !(cosA >= 0.1)) continue;      // the box must lie well inside a half-space (it must not reach the origin)
+            sinA = sqrt(fmax(0.0, 1.0 - cosA * cosA));
+        } else {
+            // Metal (material.zig:79-88): unit(reflect(d, n) + fuzz * rnd).  reflect is an isometry in d and
+            // |reflect(d0, n) - reflect(d0, n0)| <= 4 |n - n0| for unit vectors, so the vector before normalisation lies
+            // within w = |d - d0| + 4 eps + sqrt(3) fuzz of the unit vector reflect(d0, n0): a cone of half-angle asin(w).
+            // |d - d0| <= (Rl + Rp + e_d + e_o) / |Dv| (1 + small): directions from lens points to footprint points.
+            const double fuzz = fabs((double)mat[order[ic]].w);
+            double dn = 0.0;
+            for (int i = 0; i < 3; ++i) dn += Dv[i] * n0[i];
+            dn /= lenDv;
+            double al = 0.0;
+            for (int i = 0; i < 3; ++i) { ax[i] = Dv[i] / lenDv - 2.0 * dn * n0[i]; al += ax[i] * ax[i]; }
+            al = sqrt(al);
+            if (!(al > 0.5)) continue;
+            for (int i = 0; i < 3; ++i) ax[i] /= al;
+            const double dd_raw = (C.Rl + C.Rp + C.e_d + C.e_o) / lenDv;    // sin of the largest angle between d and d0
+            if (!(dd_raw <= 0.2)) continue;
+            const double dd = 1.02 * dd_raw;                                 // |d - d0| = 2 sin(angle / 2) <= 1.005 sin(angle) there
+            const double w = fmax(dd + 4.0 * eps + 1.7320508075688773 * fuzz * (1.0 + 1e-6) + 1e-5, 0.02); // (not narrower than the run-time check can tell)
+            if (!(w <= 0.95)) continue;
+            sinA = w;
+            cosA = sqrt(1.0 - w * w);
         }
-        if (!ok || !(cosA >= 0.1)) continue;      // the box must lie well inside a half-space (it must not reach the origin)
-        sinA = sqrt(fmax(0.0, 1.0 - cosA * cosA));
         Sj = order[ic];
     }
     doB = doB && Sj != kListEnd;
@@ -929,6 +955,8 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     L[kListP0] = __float_as_uint((float)p0[0]); L[kListP0 + 1] = __float_as_uint((float)p0[1]); L[kListP0 + 2] = __float_as_uint((float)p0[2]);
     const double rc = 0.98 * rho_p;
     L[kListRho2] = __float_as_uint((float)(rc * rc) * (1.0f - 1e-6f));
+    L[kListAxis] = __float_as_uint(axf[0]); L[kListAxis + 1] = __float_as_uint(axf[1]); L[kListAxis + 2] = __float_as_uint(axf[2]);
+    L[kListCos] = __float_as_uint(fminf((float)cosA * (1.0f + 1e-5f) + 1e-5f, 2.0f)); // what pt_primary demands of each path's direction
     L[kListS] = Sj;
 }
 
@@ -1015,9 +1043,11 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                                 hit0 = (uint32_t)hit;
                                 ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState1 << kTagShift) | hit0));
                                 rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(drawn));
-                                // one more bounce here if this hit is the one list B was built for: the pixel's main sphere, within the patch
+                                // one more bounce here if this ray is one list B was built for: it leaves the pixel's main sphere
+                                // within the patch and runs inside the cone
                                 const V3 dp = vsub(p, v3(__uint_as_float(L[kListP0]), __uint_as_float(L[kListP0 + 1]), __uint_as_float(L[kListP0 + 2])));
-                                if (hit0 == L[kListS] && vlen2(dp) <= __uint_as_float(L[kListRho2])) {
+                                const V3 axis = v3(__uint_as_float(L[kListAxis]), __uint_as_float(L[kListAxis + 1]), __uint_as_float(L[kListAxis + 2]));
+                                if (hit0 == L[kListS] && vlen2(dp) <= __uint_as_float(L[kListRho2]) && vdot(nd, axis) >= __uint_as_float(L[kListCos])) {
                                     o = p; d = nd;
                                     continue;
                                 }
@@ -1758,7 +1788,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             }
             hipLaunchKernelGGL(pt_primary_lists, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
                                cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
-                               ctx->nspheres, (const uint32_t *)ctx->d_kind, cfg->t_min,
+                               ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min,
                                (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u, d_lists);
             HIP_TRY(ctx, hipGetLastError());
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
