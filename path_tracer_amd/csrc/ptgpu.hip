@@ -706,6 +706,12 @@ struct ListCam {
     double O[3], llc[3], H[3], V[3];
     double Rl, Rp, e_o, e_d;
 };
+#ifndef PT_METAL_CONE
+#define PT_METAL_CONE 1.0 // second-bounce lists off a metal: cone width = spread of the incoming directions + this x the turn of the normal (4 = the bound; pt_primary checks each path; 1 / 2 / 4: 46.9 / 47.6 / 48.0 ms per 256 samples of the headline frame)
+#endif
+#ifndef PT_GLASS_CONE
+#define PT_GLASS_CONE 1.0 // (0.8 / 1.5 / 3: 47.5 / 48.1 / 48.4 ms per 256 samples of the headline frame) second-bounce lists behind a dielectric: cone width in units of (spread of the incoming directions + turn of the normal)
+#endif
 #ifndef PT_PATCH_FACTOR
 #define PT_PATCH_FACTOR 1.05 // measured on the headline frame, 0.5 / 0.75 / 1.05 / 1.3 / 2 / 3: 60.1 / 57.1 / 56.8 / 57.5 / 58.2 / 59.5 ms per 256 samples; second-bounce lists: patch radius in units of the camera rays' footprint on the sphere (a choice: pt_primary checks each hit point)
 #endif
@@ -812,14 +818,14 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     bool doB = act && second_bounce && count != 0u; // this thread builds list B
 
     // ---- list B: what a ray scattered off the pixel's main sphere can hit ---------------------------------
-    // S = a Lambertian or Metal sphere the pixel's CENTRAL ray hits (material.zig:43-51: direction unit(n + rnd), rnd in
-    // [0,1)^3; material.zig:79-88: unit(reflect(d, n) + fuzz rnd)).  The list is built for rays that start within rho_p of the central hit point p0 on S and run
+    // S = a sphere the pixel's CENTRAL ray hits (Lambertian, material.zig:43-51: direction unit(n + rnd), rnd in [0,1)^3;
+    // Metal, material.zig:79-88: unit(reflect(d, n) + fuzz rnd); Dielectric: the refracted direction).  The list is built for rays that start within rho_p of the central hit point p0 on S and run
     // inside a cone (axis a, half-angle alpha) — pt_primary checks both of each path's own hit point and direction before it
     // uses the list, so patch and cone are choices, not bounds; they are chosen to hold nearly all of the pixel's rays: with
     // n + rnd inside the box [n0 - eps, n0 + 1 + eps]^3 (eps: the turn of the normal over the patch + f32 rounding),
     // i.e. inside the circular cone (axis a, half-angle alpha) around that box.  A sphere (c, r) such a ray hits has
     // its centre within r' + rho_p of the cone with apex p0:  angle(c - p0, a) <= alpha + asin((r' + rho_p) / |c - p0|).
-    // Candidates for S: the Lambertian and Metal spheres of list A the central ray enters (near root beyond t_min), nearest first;
+    // Candidates for S: the spheres of list A the central ray enters (near root beyond t_min), nearest first;
     // the first one whose patch is flat enough for a cone wins (a small sphere in front of the ground is too curved under
     // a wide lens: the ground behind it then gets the list, for the pixel's rays that pass the small one).
     const double lenDv = sqrt(DD), tau_min = (double)t_min / lenDv;
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     uint32_t order[kNear], ncand = 0;
     for (uint32_t i = 0; doB && i < count; ++i) {
         const uint32_t j = L[i];
-        if (kind[j] > 1u) continue;   // Lambertian or Metal: their scattered rays fill a cone (below)
+        if (kind[j] > 2u) continue;   // every kind: their scattered rays fill a cone, or mostly do (below)
         const ListSphere &S = sph[j];
         const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
         const double disc = xd * xd - DD * (S.xx - (double)S.r * (double)S.r);
@@ -890,6 +896,29 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
             }
             if (!ok || !(cosA >= 0.1)) continue;      // the box must lie well inside a half-space (it must not reach the origin)
             sinA = sqrt(fmax(0.0, 1.0 - cosA * cosA));
+        } else if (kind[order[ic]] == 2u) {
+            // Dielectric (material.zig:129-167) seen from outside: the refracted ray, which most paths take (the reflected ones
+            // fail pt_primary's direction check and go on in the megakernel).  The cone is a guess around refract(d0, n0),
+            // as wide as the incoming spread and the turn of the normal suggest.
+            double dn = 0.0;
+            for (int i = 0; i < 3; ++i) dn += Dv[i] * n0[i];
+            dn /= lenDv;
+            if (!(dn < 0.0)) continue;                        // from inside: not handled
+            const double eta = (double)mat[order[ic]].x;      // 1 / refraction index (the table holds it)
+            const double cos_t = fmin(-dn, 1.0);
+            double rp[3], rp2 = 0.0;
+            for (int i = 0; i < 3; ++i) { rp[i] = eta * (Dv[i] / lenDv + cos_t * n0[i]); rp2 += rp[i] * rp[i]; }
+            if (!(rp2 < 1.0)) continue;
+            const double par = -sqrt(1.0 - rp2);
+            double al = 0.0;
+            for (int i = 0; i < 3; ++i) { ax[i] = rp[i] + par * n0[i]; al += ax[i] * ax[i]; }
+            al = sqrt(al);
+            if (!(al > 0.5)) continue;
+            for (int i = 0; i < 3; ++i) ax[i] /= al;
+            const double w = PT_GLASS_CONE * ((C.Rl + C.Rp + C.e_d + C.e_o) / lenDv + eps) + 0.02;
+            if (!(w <= 0.95)) continue;
+            sinA = w;
+            cosA = sqrt(1.0 - w * w);
         } else {
             // Metal (material.zig:79-88): unit(reflect(d, n) + fuzz * rnd).  reflect is an isometry in d and
             // |reflect(d0, n) - reflect(d0, n0)| <= 4 |n - n0| for unit vectors, so the vector before normalisation lies
@@ -907,7 +936,7 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
             const double dd_raw = (C.Rl + C.Rp + C.e_d + C.e_o) / lenDv;    // sin of the largest angle between d and d0
             if (!(dd_raw <= 0.2)) continue;
             const double dd = 1.02 * dd_raw;                                 // |d - d0| = 2 sin(angle / 2) <= 1.005 sin(angle) there
-            const double w = fmax(dd + 4.0 * eps + 1.7320508075688773 * fuzz * (1.0 + 1e-6) + 1e-5, 0.02); // (not narrower than the run-time check can tell)
+            const double w = fmax(dd + PT_METAL_CONE * eps + 1.7320508075688773 * fuzz * (1.0 + 1e-6) + 1e-5, 0.02); // (not narrower than the run-time check can tell)
             if (!(w <= 0.95)) continue;
             sinA = w;
             cosA = sqrt(1.0 - w * w);
