@@ -264,7 +264,7 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took.
  *
  * PT_LIMIT_PRIMARY_BYTES (default 24 GiB; 0 switches the primary pass off): upper bound of the device
- * buffer of the primary pass: one 32-byte record per path of a launch plus 160 B of candidate lists per
+ * buffer of the primary pass: one 32-byte record per path of a launch plus 176 B of candidate lists per
  * pixel.  The primary pass traces every camera ray against the few spheres its pixel's rays can reach
  * (a conservative per-pixel list built per launch) and shades the first hit; the megakernel continues the
  * paths from the records, so its scan over all spheres only serves scattered rays.  Same closest hits,
@@ -272,8 +272,8 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * allocated at the size a render needs, not at the limit.  ptgpu_render_sum_device_noalloc never runs the
  * primary pass (its records would not fit the static scratch).
  *
- * PT_LIMIT_PRIMARY_BOUNCES (1 or 2, default 2): 2 lets the primary pass also trace the ray scattered off the sphere a
- * pixel mainly shows (a Lambertian first hit near the pixel's central hit point) against a second per-pixel list;
+ * PT_LIMIT_PRIMARY_BOUNCES (1 or 2, default 2): 2 lets the primary pass also trace the ray the sphere a pixel mainly
+ * shows sends on (scattered, mirrored or refracted from near the pixel's central hit point) against a second per-pixel list;
  * 1 stops it after the camera ray.  Results do not depend on it. */
 enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1, PT_LIMIT_PRIMARY_BOUNCES = 2 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
