@@ -5,9 +5,10 @@ A "step" = one full render of BASELINE configs[2]: scene 21 (488 spheres), 1920x
 pixel (subpixels 4 x rays_per_subsample 256), depth 50, seed 456, with the scene/camera already
 resident in HBM and the fp32 radiance sums left in HBM.
 N > 1 GPUs: STRONG scaling of that same frame (BASELINE's metric: "scene 21 1080p, 1/2/4/8 GPUs") by
-sample-range split — rank g traces samples [g*1024/N, (g+1)*1024/N) of every pixel, then ONE RCCL
-reduce(SUM) of the fp32 sum buffers to rank 0 (inside the timed region).  `--weak` keeps the per-GPU
-work fixed instead (N x 1024 paths per pixel).  value = paths traced by all ranks / max-over-ranks
+interleaved 256-pixel tiles — rank g traces all 1024 samples of the tiles t with t % N == g, other pixels
+stay 0 — then ONE RCCL reduce(SUM) of the fp32 sum buffers to rank 0 (inside the timed region), which
+assembles the one-GPU frame bit for bit.  `--split samples` splits the sample range of every pixel
+instead; `--weak` keeps the per-GPU work fixed (N x 1024 paths per pixel, sample split).  value = paths traced by all ranks / max-over-ranks
 wall time.
 
 Rank 0 prints one JSON line (contract in the task statement) with `roofline` (FP32 VALU) and,
@@ -80,15 +81,18 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=456)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="samples per GPU work item; 0 = 16 on one GPU (and for --weak), max(4, 16/N) when N ranks share one frame "
-                         "(a rank's launch is N times shorter, so its tail must be: measured at 128 samples/rank, chunk 4/8/16/32 = "
-                         "51.1/51.7/52.5/54.7 ms against 50.95 ideal)")
+                    help="samples per GPU work item; 0 = 16 on one GPU (and for --weak), 8 when N ranks share one frame by tiles, "
+                         "max(4, 16/N) by samples (a rank's launch is N times shorter, so its tail must be: measured at one rank's "
+                         "eighth, tiles, chunk 8 / 16 = 22.9 / 23.7 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spheres", type=int, default=0,
                     help="0 (default) = scene 21, the headline config; N > 0 = the synthetic random-sphere scene of N spheres "
                          "(BASELINE configs[4] uses 100000 with --spp 64 --split tiles)")
-    ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
-                    help="multi-GPU partition of the frame: sample ranges of every pixel, or interleaved 256-pixel tiles")
+    ap.add_argument("--split", choices=["samples", "tiles"], default=None,
+                    help="multi-GPU partition of the frame: interleaved 256-pixel tiles (default: a rank then builds the candidate "
+                         "lists of its own pixels only, and the frame equals the one-GPU frame bit for bit) or sample ranges of "
+                         "every pixel (default with --weak); measured on one GPU at one rank's eighth of the headline frame: "
+                         "22.9 ms (tiles) / 25.4 ms (samples) against 22.8 = 182.5 / 8")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling (sample split only): every rank traces 4 x spp paths per pixel of a frame of N x 4 x spp; "
                          "default is strong scaling: ONE frame of 4 x spp paths per pixel shared by the N ranks")
@@ -117,8 +121,10 @@ def main():
 
     img = host.Image(args.width)
     weak = args.weak
+    if args.split is None:
+        args.split = "samples" if weak else "tiles"
     if args.chunk == 0:
-        args.chunk = 16 if (world == 1 or weak) else max(4, 16 // world)
+        args.chunk = 16 if (world == 1 or weak) else (8 if args.split == "tiles" else max(4, 16 // world))
     if weak and args.split != "samples":
         raise SystemExit("bench.py: --weak needs --split samples")
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=args.spp * (world if weak else 1), rebounds=args.depth)

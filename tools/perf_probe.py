@@ -18,7 +18,9 @@ def main():
     else:
         sp = host.Scene().setupScene(456, scene).spheres; cam = host.Camera.preset(scene).pod
     img = host.Image(width)
-    cfg = host.make_pt_config(img, host.RayTracerConfig(subpixels=4, rays_per_subsample=spp, rebounds=depth), seed=456, chunk=chunk)
+    tiles = os.environ.get("PROBE_TILES")  # "count,index": one owner's share of an interleaved 256-pixel tile split
+    tkw = dict(tile_pixels=256, tile_count=int(tiles.split(",")[0]), tile_index=int(tiles.split(",")[1])) if tiles else {}
+    cfg = host.make_pt_config(img, host.RayTracerConfig(subpixels=4, rays_per_subsample=spp, rebounds=depth), seed=456, chunk=chunk, **tkw)
     g = GpuContext(0)
     info = g.device_info()
     g.set_scene(sp); g.set_camera(cam)
