@@ -263,7 +263,7 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * pixels, one kernel launch each, through the same buffer; the result is bit-identical (a pixel's
  * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took.
  *
- * PT_LIMIT_PRIMARY_BYTES (default 24 GiB; 0 switches the primary pass off): upper bound of the device
+ * PT_LIMIT_PRIMARY_BYTES (default 96 GiB; 0 switches the primary pass off): upper bound of the device
  * buffer of the primary pass: one 32-byte record per path of a launch plus 176 B of candidate lists per
  * pixel.  The primary pass traces every camera ray against the few spheres its pixel's rays can reach
  * (a conservative per-pixel list built per launch) and shades the first hit; the megakernel continues the

@@ -27,6 +27,7 @@ PT_ERR_RCCL = -11
 PT_LIMIT_PARTIAL_BYTES = 0
 PT_LIMIT_PRIMARY_BYTES = 1
 PT_LIMIT_PRIMARY_BOUNCES = 2
+PT_PRIMARY_BYTES_DEFAULT = 96 << 30   # the library's default for PT_LIMIT_PRIMARY_BYTES
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2

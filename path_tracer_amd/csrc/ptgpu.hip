@@ -1355,7 +1355,7 @@ struct ptgpu_ctx {
     int resident[2][2] = {{0, 0}, {0, 0}};           // [det][multi]: workgroups per CU the occupancy query reports
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
     uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
-    uint64_t primary_cap = 24ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
+    uint64_t primary_cap = 96ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
     uint32_t primary_bounces = 2;                    // PT_LIMIT_PRIMARY_BOUNCES: 1 = camera rays only, 2 = also the rays scattered off each pixel's main sphere
     unsigned char *d_prim = nullptr; size_t prim_bytes = 0; // primary-pass records + candidate lists
     void *d_lsph = nullptr; size_t lsph_bytes = 0;          // ListSphere per sphere (pt_list_prep)

@@ -1,7 +1,7 @@
 """BASELINE configs[3] and configs[4] at size, one rank's share each (what one of 8 GPUs renders).
 
 configs[3]: scene 21, 3840x2160, 4096 paths/pixel, depth 50, sample-range split: one rank's 512 samples of every
-pixel (3.2 GB of chunk partials at chunk 16, 136 GB of primary-pass records -> six segments under the limits), spot pixels
+pixel (3.2 GB of chunk partials at chunk 16, 136 GB of primary-pass records -> two segments under the limits), spot pixels
 against the oracle under the same chunking, and exact additivity of two adjacent 512-sample ranges.
 configs[4]: 100 000 spheres, 1920x1080, 256 paths/pixel, depth 50, interleaved 256-pixel tiles, one of 8 owners,
 spot pixels against the oracle; pixels of the other owners stay untouched.
@@ -41,9 +41,9 @@ def test_config3_one_rank_share_4k_512_of_4096(orc, gpu):
     got = gpu.render_sum(share())
     st = gpu.stats()
     assert st.paths == 3840 * 2160 * 512 and st.not_unit == 0 and 1.8 < st.rays / st.paths < 2.6
-    # 3.2 GB of chunk partials through the 2 GiB PT_LIMIT_PARTIAL_BYTES buffer would be two segments; the primary
-    # pass's 136 GB of path records (32 B x 4.35e9 paths) through its 24 GiB PT_LIMIT_PRIMARY_BYTES buffer make it six
-    assert st.segments == 6 and 0.9 * st.paths < st.primary_rays <= st.paths
+    # 3.2 GB of chunk partials through the 2 GiB PT_LIMIT_PARTIAL_BYTES buffer: two segments (the primary pass's 136 GB
+    # of path records, 32 B x 4.35e9 paths, would also need two under its 96 GiB PT_LIMIT_PRIMARY_BYTES)
+    assert st.segments == 2 and 0.9 * st.paths < st.primary_rays <= st.paths
     rng = np.random.default_rng(33)
     flat = got.reshape(-1, 3)
     for idx in rng.integers(0, img.num_pixels, 16):

@@ -20,7 +20,7 @@ def _both(gpu, cfg, expect_primary=True):
     be identical"""
     from path_tracer_amd import _lib
     try:
-        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT)
         gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, 2)
         on = gpu.render_sum(cfg, allow_not_unit=True)
         st_on = gpu.stats()
@@ -31,7 +31,7 @@ def _both(gpu, cfg, expect_primary=True):
         off = gpu.render_sum(cfg, allow_not_unit=True)
         st_off = gpu.stats()
     finally:
-        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT)
         gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BOUNCES, 2)
     assert st_off.primary_rays == 0 and st_off.list2_rays == 0 and st_on1.list2_rays == 0
     assert st_on1.primary_rays == st_on.primary_rays
@@ -102,7 +102,7 @@ def test_segments_of_the_record_buffer_are_bit_identical(gpu):
         assert st.segments == 1 and st.primary_rays == 0
         np.testing.assert_array_equal(none, one)
     finally:
-        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 24 << 30)
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT)
 
 
 def _random_camera(rng, host, aspect):
