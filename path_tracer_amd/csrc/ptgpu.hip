@@ -473,11 +473,11 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                 if (cnt > avail) { pool_next = fresh + (cnt - avail); pool_end = fresh + kItemBatch; }
                 else pool_next += cnt;
                 if (want) {
+                    const uint32_t item = item_;
                     // A lane without a path parks on a NaN direction: no filter compare passes, so it
                     // adds no candidates and no exact-pass iterations to its wave.
                     o = v3(0.f, 0.f, 0.f); d = v3(kNaN, kNaN, kNaN);
-                    if (item_ < total_items) {
-                        const uint32_t item = item_;
+                    if (item < total_items) {
                         const uint32_t k = P.div_npix.div(item);
                         const uint32_t po = item - k * P.npix;
                         pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
@@ -490,9 +490,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
                         out_slot = P.direct ? pixel : item; // frame[pixel] or part[k][po]
                         accum = v3(0.f, 0.f, 0.f);
                         has_item = pixel < P.idx_stop;      // the owner's last tile may be cut by the range:
-                        // a mask of 0 = nothing left to do here: pt_primary settled every sample of the item and wrote its sum
-                        if (PRIMARY && P.use_mask && hmask == 0u) has_item = false;
-                        if (!has_item) s_end = sample;      // an empty item — the lane asks again (next round / next step)
+                        if (!has_item) s_end = sample;      // an empty item — the lane idles this step and asks again
                         n_paths += s_end - sample;
                     } else {
                         alive = false;
@@ -569,7 +567,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         }
         PT_STAMP(tP1);
         PT_SUB_ACC(3, tP0, tP1);
-        if (!PRIMARY || round == 15) break;   // (rounds go on while a lane found its item used up or settled: sky rows are made of those)
+        if (!PRIMARY || round == 1) break;
         if (__ballot(alive && need_path) == 0ull) break;
         } // rounds
         if (MULTI_TILE) {
@@ -998,8 +996,7 @@ template <bool DET>
 __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
     // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
-    __shared__ float4 s_col[256];
-    uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0, settled_paths = 0;
+    uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
         const uint32_t item = P.div_chunk.div(r), jj = r - item * P.chunk;
         const uint32_t k = P.div_npix.div(item), po = item - k * P.npix;
@@ -1007,7 +1004,6 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
         const uint32_t first = P.s0 + k * P.chunk;
         const uint32_t sample = first + jj;
         bool look = false; // the megakernel has to look at this path's record (a state to continue, or a dropped sample)
-        V3 fin = v3(0.f, 0.f, 0.f);
         if (pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
             typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
             rng.init(P.seed_lo, P.seed_hi);
@@ -1105,40 +1101,16 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             P.rec[2u * (size_t)r] = ra;
             if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
             look = (__float_as_uint(ra.w) >> kTagShift) != kTagFinal;
-            fin = v3(ra.x, ra.y, ra.z);
         }
         if (P.use_mask) { // 64 % chunk == 0: an item's samples sit in one wave, lanes [lane - jj, lane - jj + chunk)
-            const uint32_t lane = threadIdx.x & 63u;
             const unsigned long long m = __ballot(look);
-            const uint32_t mask = (uint32_t)(m >> (lane - jj)) & (uint32_t)((1ull << P.chunk) - 1ull);
-            const uint32_t nvalid = (pixel < P.idx_stop && first < P.s1) ? min(P.chunk, P.s1 - first) : 0u; // samples of this item
-            const bool settled = mask == 0u && nvalid != 0u;          // every sample ended here: the item never goes to the megakernel
-            if (__ballot(settled) != 0ull) {
-                // its partial sum, in sample order as the megakernel would form it (renderers/ppm_image.zig:67): the colours
-                // go through LDS (this wave's 64 slots; LDS operations of one wave complete in order), the item's first lane adds them up
-                s_col[threadIdx.x] = make_float4(fin.x, fin.y, fin.z, 0.f);
-                __builtin_amdgcn_wave_barrier();
-                if (settled && jj == 0u) {
-                    V3 acc = v3(0.f, 0.f, 0.f);
-                    for (uint32_t j = 0; j < nvalid; ++j) {
-                        const float4 cj = s_col[threadIdx.x + j];
-                        acc = vadd(acc, v3(cj.x, cj.y, cj.z));
-                    }
-                    float *dst = P.part + 3ull * (P.direct ? pixel : item);
-                    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
-                    settled_paths += nvalid;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (jj == 0u) P.item_mask[item] = mask;
+            if (jj == 0u) P.item_mask[item] = (uint32_t)(m >> (threadIdx.x & 63u)) & (uint32_t)((1ull << P.chunk) - 1ull);
         }
     }
-    const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit),
-                             w_settled = wave_sum_u64(settled_paths);
+    const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
     if ((threadIdx.x & 63u) == 0u) {
         if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays + w_rays2); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
         if (w_rays2) atomicAdd(&P.counters[CNT_LIST2_RAYS], w_rays2);
-        if (w_settled) atomicAdd(&P.counters[CNT_PATHS], w_settled);
         if (w_cands) atomicAdd(&P.counters[CNT_CANDS], w_cands);
         if (w_nu) atomicAdd(&P.counters[CNT_NOT_UNIT], w_nu);
     }
