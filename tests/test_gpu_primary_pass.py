@@ -74,8 +74,12 @@ def test_ranges_tiles_samples_and_aovs_on_off(gpu):
     for kw in (dict(chunk=0), dict(chunk=5, istart=777, istop=4001), dict(chunk=4, tile_pixels=256, tile_count=3, tile_index=2),
                dict(chunk=3, sample_start=2, sample_stop=11), dict(chunk=1), dict(chunk=4, illumination=1), dict(chunk=4, illumination=2)):
         _both(gpu, host.make_pt_config(img, rt, seed=9, **kw))
-    for rebounds in (0, 1):
+    for rebounds in (0, 1, 2):
         _both(gpu, host.make_pt_config(img, host.RayTracerConfig(subpixels=2, rays_per_subsample=6, rebounds=rebounds), seed=9, chunk=4))
+    # every chunk size that gets per-item masks (it divides 64 and is <= 32), and some that do not; 70 samples: a ragged last chunk
+    rt70 = host.RayTracerConfig(subpixels=2, rays_per_subsample=35, rebounds=50)
+    for chunk in (1, 2, 8, 16, 32, 64, 7, 70, 33):
+        _both(gpu, host.make_pt_config(img, rt70, seed=10, chunk=chunk, istart=500, istop=2500))
 
 
 def test_segments_of_the_record_buffer_are_bit_identical(gpu):
