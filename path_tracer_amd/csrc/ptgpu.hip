@@ -61,6 +61,10 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 #ifndef PT_SUB
 #define PT_SUB 4
 #endif
+#ifndef PT_REFILL_ROUNDS
+#define PT_REFILL_ROUNDS 2 // with primary-pass records: refill rounds per ray step while some lane used its item up (rows of sky are all such
+                           // items).  Measured on the headline frame, 2 / 4 / 16 rounds: lane utilisation 0.966 / 0.983 / 0.993 but 175.1 / 175.2 / 179.3 ms
+#endif
 #ifndef PT_WORDS_PER_ITER
 #define PT_WORDS_PER_ITER 4 // mask words (x32 tests) per unrolled scan-loop iteration; measured 1/2/4/8: 432.3/429.8/428.6/433.0 ms
 #endif
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         // ---- phase A: refill lanes whose path has ended -------------------------
         PT_STAMP(tA0);
         // With primary-pass records a lane can use up its item while starting a path (every remaining sample
-        // ended in the primary pass): such lanes get one more round — a new item and its records — before the
-        // wave goes into the scan.
+        // ended in the primary pass): such lanes get more rounds — a new item and its records — before the
+        // wave goes into the scan (PT_REFILL_ROUNDS).
         for (int round = 0;; ++round) {
         if (alive && need_path && sample == s_end) {
             if (has_item) {
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         }
         PT_STAMP(tP1);
         PT_SUB_ACC(3, tP0, tP1);
-        if (!PRIMARY || round == 1) break;
+        if (!PRIMARY || round == PT_REFILL_ROUNDS - 1) break;
         if (__ballot(alive && need_path) == 0ull) break;
         } // rounds
         if (MULTI_TILE) {
