@@ -996,8 +996,24 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
 // One thread per path of the launch, in record order (item-major, the item's samples consecutive): the
 // camera ray (renderers/ppm_image.zig:50-51,61-63), Scene.is_hit over the pixel's list, one radiance step
 // (illumination.zig:76-90 at depth 0).
-template <bool DET>
+template <bool DET, bool MULTI_TILE>
 __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
+    // scenes of one tile keep the sphere tables in LDS (19 KiB; the grid-stride loop reuses them): the candidate loop's
+    // geometry reads were dependent global loads, and the kernel waited on memory 42 % of its wave cycles
+    __shared__ float4 s_geom[MULTI_TILE ? 1 : kTile];
+    __shared__ float4 s_mat[MULTI_TILE ? 1 : kTile];
+    __shared__ float s_inv_radius[MULTI_TILE ? 1 : kTile];
+    __shared__ uint8_t s_kind[MULTI_TILE ? 4 : kTile];
+    if (!MULTI_TILE) {
+        for (uint32_t i = threadIdx.x; i < P.nspheres; i += 256u) {
+            s_geom[i] = P.geom[i]; s_mat[i] = P.mat[i]; s_inv_radius[i] = P.inv_radius[i]; s_kind[i] = (uint8_t)P.kind[i];
+        }
+        __syncthreads();
+    }
+    auto geom_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.geom[j] : s_geom[j]; };
+    auto mat_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.mat[j] : s_mat[j]; };
+    auto inv_radius_of = [&](uint32_t j) -> float { return MULTI_TILE ? P.inv_radius[j] : s_inv_radius[j]; };
+    auto kind_of = [&](uint32_t j) -> uint32_t { return MULTI_TILE ? P.kind[j] : (uint32_t)s_kind[j]; };
     // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
     uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0;
@@ -1039,15 +1055,23 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                     const float a = vlen2(d); // sphere.zig:68
                     float closest = P.t_max;
                     int hit = -1;
-                    const uint32_t cap = depth ? kListCapB : kListCap;
-                    for (uint32_t i = 0; i < cap; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
-                        const uint32_t j = Ld[i];
-                        if (j == kListEnd) break;
-                        const float4 g = P.geom[j];
-                        cands++;
-                        float t;
-                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
-                            if (t < closest) { closest = t; hit = (int)j; }
+                    // the whole list at once (four independent 16-byte loads), not entry by entry
+                    static_assert(kListCap == 16 && kListCapB == 16 && kListB % 4 == 0 && kListStride % 4 == 0, "lists are read as 4 x uint4");
+                    const uint4 *L4 = reinterpret_cast<const uint4 *>(Ld);
+                    const uint4 e0 = L4[0], e1 = L4[1], e2 = L4[2], e3 = L4[3];
+                    const uint32_t ent[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+                    bool more = true; // (a flag instead of a break: the sixteen steps unroll, ent[] stays in registers)
+#pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
+                        const uint32_t j = ent[i];
+                        more = more && j != kListEnd;
+                        if (more) {
+                            const float4 g = geom_of(j);
+                            cands++;
+                            float t;
+                            if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
+                                if (t < closest) { closest = t; hit = (int)j; }
+                            }
                         }
                     }
                     if (depth) rays2++; else rays++;
@@ -1061,15 +1085,15 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                                 const V3 n = vunit(vsub(p, v3(0.0f, 0.0f, -1.0f)));
                                 color = vmul(vadd(n, v3(1.0f, 1.0f, 1.0f)), 0.5f);
                             } else {                          // illumination.zig:65-69
-                                const float4 m = P.mat[hit];
-                                color = (P.kind[hit] == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
+                                const float4 m = mat_of((uint32_t)hit);
+                                color = (kind_of((uint32_t)hit) == 2u) ? v3(1.0f, 1.0f, 1.0f) : v3(m.x, m.y, m.z);
                             }
                         } else if (depth != P.rebounds) {     // depth == rebounds: illumination.zig:80-81, black
-                            const float4 g = P.geom[hit];
-                            const float4 m = P.mat[hit];
-                            const uint32_t kind = P.kind[hit];
+                            const float4 g = geom_of((uint32_t)hit);
+                            const float4 m = mat_of((uint32_t)hit);
+                            const uint32_t kind = kind_of((uint32_t)hit);
                             V3 p, n;
-                            sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, P.inv_radius[hit], p, n);
+                            sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
                             const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
                             const uint32_t drawn = rng.drawn();
                             if (depth == 0u) {
@@ -1095,8 +1119,8 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                         not_unit++;
                     } else if (depth) {
                         // v.elementwiseMul(s.attenuation) of the first hit (illumination.zig:84-85)
-                        const float4 m = P.mat[hit0];
-                        color = (P.kind[hit0] != 2u) ? vemul(color, v3(m.x, m.y, m.z)) : vemul(color, v3(1.0f, 1.0f, 1.0f));
+                        const float4 m = mat_of(hit0);
+                        color = (kind_of(hit0) != 2u) ? vemul(color, v3(m.x, m.y, m.z)) : vemul(color, v3(1.0f, 1.0f, 1.0f));
                     }
                     ra = make_float4(color.x, color.y, color.z, __uint_as_float(tag << kTagShift));
                     break;
@@ -1826,8 +1850,13 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             HIP_TRY(ctx, hipGetLastError());
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
             const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);
-            if (det) hipLaunchKernelGGL((pt_primary<true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
-            else hipLaunchKernelGGL((pt_primary<false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+            if (det) {
+                if (multi) hipLaunchKernelGGL((pt_primary<true, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+                else hipLaunchKernelGGL((pt_primary<true, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+            } else {
+                if (multi) hipLaunchKernelGGL((pt_primary<false, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+                else hipLaunchKernelGGL((pt_primary<false, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+            }
             HIP_TRY(ctx, hipGetLastError());
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg + 1u], stream));
         }
