@@ -215,9 +215,11 @@ enum {
     PT_FN_LERP = 7,        /* illumination.zig:27 in: d,p0,p1 (9)                 out: err,rgb (4)         */
     PT_FN_PHILOX = 8,      /* RNG: in: seed_lo,seed_hi,pixel,sample,block (5 x u32 bits) out: 4 floats     */
     PT_FN_SCENE_HIT_FILTERED = 9, /* scene.zig:96 as the megakernel evaluates it (LDS filter + exact pass): in/out as PT_FN_SCENE_HIT */
-    PT_FN_FILTER_BIT = 10  /* the LDS filter's verdict for one (ray, sphere) pair: in: o,d,c,r (10)  out: candidate bit,
+    PT_FN_FILTER_BIT = 10, /* the LDS filter's verdict for one (ray, sphere) pair: in: o,d,c,r (10)  out: candidate bit,
                               reference discriminant of sphere.zig:74, candidate bit of the shared-ordinate form of the
                               test (3).  Invariant: discriminant >= 0 => both bits == 1 */
+    PT_FN_SCENE_HIT_TREE = 11 /* scene.zig:96 through the sphere tree of large scenes (PT_LIMIT_TREE_MIN_SPHERES): in/out as
+                              PT_FN_SCENE_HIT; PT_ERR_UNSUPPORTED when the uploaded scene has no tree */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);
@@ -274,14 +276,24 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  *
  * PT_LIMIT_PRIMARY_BOUNCES (1 or 2, default 2): 2 lets the primary pass also trace the ray the sphere a pixel mainly
  * shows sends on (scattered, mirrored or refracted from near the pixel's central hit point) against a second per-pixel list;
- * 1 stops it after the camera ray.  Results do not depend on it. */
-enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1, PT_LIMIT_PRIMARY_BOUNCES = 2 };
+ * 1 stops it after the camera ray.  Results do not depend on it.
+ *
+ * PT_LIMIT_TREE_MIN_SPHERES (default 513 = one LDS tile of the scan + 1; 0 = never): scenes of at least this many
+ * spheres are traced through a tree of boxes over the spheres instead of the scan over all of them (scene.zig:96-110
+ * tests every sphere for every ray; the tree only skips spheres the reference's f32 test provably rejects, and the
+ * closest hit is chosen by (t, index) as the ascending scan chooses it: same hits, bit for bit).  The tree is built
+ * by ptgpu_set_scene (host, O(n log n)): set the limit before uploading the scene.  Scenes with a non-finite centre
+ * or radius, or deeper than the traversal stack (beyond ~6e7 spheres), keep the scan. */
+enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1, PT_LIMIT_PRIMARY_BOUNCES = 2, PT_LIMIT_TREE_MIN_SPHERES = 3 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
 
 /* Diagnostics. */
 /* The uploaded scene: its sphere count, and how many of them sit in mask words (32 consecutive spheres) that share
  * one centre ordinate and therefore take the filter's 5-FMA test instead of the 7-FMA one. */
 int ptgpu_scene_info(const ptgpu_ctx *ctx, uint32_t *nspheres, uint32_t *shared_ordinate_tests);
+/* The sphere tree of the uploaded scene (PT_LIMIT_TREE_MIN_SPHERES): its inner nodes (0: the scene has none and is
+ * traced by the scan) and its depth in levels. */
+int ptgpu_tree_info(const ptgpu_ctx *ctx, uint32_t *nodes, uint32_t *depth);
 int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
 const char *ptgpu_strerror(int status);
 int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */

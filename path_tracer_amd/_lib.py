@@ -27,6 +27,8 @@ PT_ERR_RCCL = -11
 PT_LIMIT_PARTIAL_BYTES = 0
 PT_LIMIT_PRIMARY_BYTES = 1
 PT_LIMIT_PRIMARY_BOUNCES = 2
+PT_LIMIT_TREE_MIN_SPHERES = 3
+PT_TREE_MIN_SPHERES_DEFAULT = 513      # the library's default: one LDS tile of the scan + 1
 PT_PRIMARY_BYTES_DEFAULT = 96 << 30   # the library's default for PT_LIMIT_PRIMARY_BYTES
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
@@ -34,11 +36,11 @@ PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
 
 (PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
- PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT) = range(11)
+ PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT, PT_FN_SCENE_HIT_TREE) = range(12)
 FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
     PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
     PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8),
-    PT_FN_FILTER_BIT: (10, 3)}
+    PT_FN_FILTER_BIT: (10, 3), PT_FN_SCENE_HIT_TREE: (6, 8)}
 
 # pt_sphere: 36 bytes
 SPHERE_DTYPE = np.dtype(
@@ -79,7 +81,7 @@ assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
            "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
-           "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_scene_info", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
+           "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_scene_info", "ptgpu_tree_info", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
            "ptgpu_abi_version",
            "ptgpu_multi_create", "ptgpu_multi_destroy", "ptgpu_multi_num_gpus", "ptgpu_multi_uses_rccl", "ptgpu_multi_ctx",
            "ptgpu_multi_set_scene", "ptgpu_multi_set_camera", "ptgpu_multi_render_sum_host", "ptgpu_multi_render_ppm",
@@ -122,6 +124,7 @@ def load():
     L.ptgpu_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_float, C.c_float]
     L.ptgpu_get_stats.argtypes = [vp, C.POINTER(pt_stats)]
     L.ptgpu_scene_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ptgpu_tree_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ptgpu_strerror.argtypes = [C.c_int]
     L.ptgpu_strerror.restype = C.c_char_p
     L.ptgpu_last_hip_error.argtypes = [vp]

@@ -119,6 +119,7 @@ static FastDiv make_fastdiv(uint32_t d) {
     return f;
 }
 
+struct TreeNode;
 struct KParams {
     Cam cam;
     V3 blend_start, blend_stop;
@@ -154,6 +155,11 @@ struct KParams {
     const uint32_t *lists;  // [npix][kListStride]: candidate spheres of each pixel slot's camera rays and of its second-bounce rays (pt_primary_lists)
     uint32_t *stack;    // [rebounds][total_threads] hit ids
     unsigned long long *counters;
+    // sphere tree (pt_megakernel<.., TREE = true>): nodes, the spheres in leaf order (geometry, original index), root ref
+    const TreeNode *tnodes;
+    const float4 *tgeom;
+    const uint32_t *tprim;
+    uint32_t troot;
 };
 
 // Pixel index of local slot `po`: the range itself, or the owner's interleaved tiles
@@ -372,6 +378,91 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 }
 
 // ---------------------------------------------------------------------------
+// Scene.is_hit over a sphere tree (scenes too large for one LDS tile)
+// ---------------------------------------------------------------------------
+// The scan above costs every ray one filter test per sphere; beyond one LDS tile the table is also restaged
+// per ray step.  For such scenes ptgpu_set_scene builds a binary tree of axis-aligned boxes over the spheres
+// (leaves of <= kTreeLeaf spheres) and each lane walks it with its own stack (LDS, word-major).  The tree only
+// selects which spheres get the exact Sphere.is_hit; the closest hit is the minimum of (t, sphere index) over
+// the spheres that pass it, which is what the reference's ascending scan with strict '<' returns
+// (scene.zig:96-110), so the outcome is the same bit for bit PROVIDED no box is skipped that holds a sphere
+// the f32 test would accept with t below the current closest.  That test can accept a ray whose line misses
+// the sphere in real arithmetic (rounding of the discriminant, sphere.zig:66-72): the accepted point
+// o + t d then lies within r' of the centre, r'^2 = r^2 + g (2 |o - c|^2 + r^2), g = kListGamma (the bound the
+// primary pass's lists use, with the same 9x reserve).  A box [lo, hi] that contains its
+// spheres (centre +- radius, rounded outwards) is therefore tested after growing it by
+//   mu = kTreeKappa * m,   m = max_axis max(|lo - o|, |hi - o|)  >=  r  and  >= |o - c| / sqrt 3  for each of its spheres,
+// kTreeKappa = 8e-3 >= sqrt(g) (sqrt 6 + 1) = 6.9e-3 >= (r' - r) / m; the rest covers the slab arithmetic
+// (every term is a difference to o, so its rounding is relative to m as well).  A ray on the boundary of
+// a grown box (0 x inf = NaN in a slab) may go either way: it is >= mu away from every sphere in it.
+struct TreeNode { float4 a, b, c; uint4 ch; }; // boxes of the two children: a = (lo0, hi0.x), b = (hi0.yz, lo1.xy), c = (lo1.z, hi1); ch.x, ch.y = child refs
+constexpr uint32_t kTreeLeaf = 4;          // spheres per leaf (at most)
+constexpr uint32_t kTreeStack = 24;        // stack entries per lane = deepest tree walked (set_scene falls back to the scan beyond it)
+constexpr uint32_t kTreeLeafBit = 0x80000000u, kTreeNone = 0xffffffffu; // leaf ref: bit 31 | (count - 1) << 29 | first slot of the leaf arrays
+constexpr float kTreeKappa = 8e-3f;
+
+__device__ __forceinline__ bool tree_box(V3 o, V3 inv, float lox, float loy, float loz, float hix, float hiy, float hiz, float t_lo, float t_hi,
+                                         float &t_near) {
+    const float lx = lox - o.x, hx = hix - o.x, ly = loy - o.y, hy = hiy - o.y, lz = loz - o.z, hz = hiz - o.z;
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(lx), fabsf(hx)), fmaxf(fabsf(ly), fabsf(hy))), fmaxf(fabsf(lz), fabsf(hz)));
+    const float mu = kTreeKappa * m;
+    const float t1x = (lx - mu) * inv.x, t2x = (hx + mu) * inv.x;
+    const float t1y = (ly - mu) * inv.y, t2y = (hy + mu) * inv.y;
+    const float t1z = (lz - mu) * inv.z, t2z = (hz + mu) * inv.z;
+    t_near = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), t_lo));
+    const float t_far = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), t_hi));
+    return t_near <= t_far;
+}
+
+// s_stack: kTreeStack words per lane, word-major (entry e of thread tid at [e * kBlock + tid]).
+__device__ __forceinline__ void scene_is_hit_tree(const TreeNode *__restrict__ nodes, const float4 *__restrict__ tgeom, const uint32_t *__restrict__ tprim,
+                                                  uint32_t root, uint32_t *s_stack, uint32_t tid, bool active, V3 o, V3 d, float a, float t_min, float t_max,
+                                                  float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters) {
+    // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
+    const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // (a lane without a ray stays out: its parked NaN direction would pass every box — min/max drop NaN operands)
+    uint32_t cur = active ? root : kTreeNone, sp = 0;
+    for (;;) {
+        if (cur == kTreeNone && sp > 0u) cur = s_stack[--sp * kBlock + tid];
+        if (__ballot(cur != kTreeNone) == 0ull) break;
+        n_iters++;
+        if (cur == kTreeNone) {
+            // nothing pending for this lane: it waits for the wave
+        } else if (cur & kTreeLeafBit) {
+            const uint32_t first = cur & 0x1fffffffu, cnt = ((cur >> 29) & 3u) + 1u;
+#pragma unroll
+            for (uint32_t k = 0; k < kTreeLeaf; ++k) {
+                if (k < cnt) {
+                    const float4 g = tgeom[first + k];
+                    const uint32_t id = tprim[first + k];
+                    n_cands++;
+                    float t;
+                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
+                        // the scan's outcome: smallest t, and among equal t the lowest sphere index
+                        if (t < closest || (t == closest && (int)id < hit)) { closest = t; hit = (int)id; }
+                    }
+                }
+            }
+            cur = kTreeNone;
+        } else {
+            const TreeNode *nd = nodes + cur;
+            const float4 A = nd->a, B = nd->b, C = nd->c;
+            const uint4 ch = nd->ch;
+            float n0, n1;
+            const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
+            const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1; // nearer box first: a hit found there shortens (t_min, closest) for the boxes below the other
+                s_stack[sp++ * kBlock + tid] = first0 ? ch.y : ch.x;
+                cur = first0 ? ch.x : ch.y;
+            } else {
+                cur = h0 ? ch.x : (h1 ? ch.y : kTreeNone);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // the megakernel
 // ---------------------------------------------------------------------------
 // MULTI_TILE: the filter table is larger than one LDS tile and is restaged tile by tile in
@@ -381,10 +472,13 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 // through the scalar cache instead (s_load_dwordx16 into SGPR operands: no VGPRs, no LDS reads)
 // was measured 15 % slower on MI355X — 16 B per wave per test saturates the scalar cache, which
 // several CUs share, long before LDS.
-template <bool DET, bool MULTI_TILE, bool PRIMARY>
+// TREE (with MULTI_TILE, i.e. tables in global memory): Scene.is_hit walks the sphere tree instead of scanning; no filter
+// table in LDS, no barriers — s_mask is the lanes' traversal stacks.
+template <bool DET, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
-    __shared__ float4 s_filt[kTile + kSub];                 // (cx, cz, T, cy) filter records of the current tile
-    __shared__ uint32_t s_mask[mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
+    static_assert(!TREE || MULTI_TILE, "the tree variant reads the sphere tables from global memory");
+    __shared__ float4 s_filt[TREE ? 1 : kTile + kSub];      // (cx, cz, T, cy) filter records of the current tile
+    __shared__ uint32_t s_mask[TREE ? kTreeStack * kBlock : mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
     __shared__ float s_ycy[kTile / 32];                     // per mask word of the tile: shared centre ordinate, or NaN
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
@@ -574,7 +668,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         if (!PRIMARY || round == PT_REFILL_ROUNDS - 1) break;
         if (__ballot(alive && need_path) == 0ull) break;
         } // rounds
-        if (MULTI_TILE) {
+        if (MULTI_TILE && !TREE) {
             if (!__syncthreads_or(alive ? 1 : 0)) break;
         } else {
             if (__ballot(alive) == 0ull) break;
@@ -587,8 +681,11 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
-                                          n_cands, n_flush_iters, t_flush);
+        if (TREE)
+            scene_is_hit_tree(P.tnodes, P.tgeom, P.tprim, P.troot, s_mask, tid, alive && !need_path, o, d, a, P.t_min, P.t_max, closest, hit, n_cands, n_flush_iters);
+        else
+            scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
+                                              n_cands, n_flush_iters, t_flush);
         const bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
         if (tracing) n_rays++;
         n_wave_steps++;
@@ -1344,6 +1441,27 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
     w[0] = (float)hit; w[1] = (hit >= 0) ? closest : 0.f; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
 }
 
+// PT_FN_SCENE_HIT_TREE: the same through the sphere tree (same record).
+__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *in, float *out, uint32_t n, const TreeNode *nodes, const float4 *tgeom,
+                                                                  const uint32_t *tprim, uint32_t root, const float4 *g_geom, float t_min, float t_max) {
+    __shared__ uint32_t s_stack[kTreeStack * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    const bool live = i < n;
+    const float *r = in + (size_t)(live ? i : 0) * 6;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const float a = vlen2(d);
+    float closest = t_max;
+    int hit = -1;
+    uint32_t n_cands = 0, n_iters = 0;
+    scene_is_hit_tree(nodes, tgeom, tprim, root, s_stack, tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    if (!live) return;
+    float *w = out + (size_t)i * 8;
+    V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
+    if (hit >= 0) { const float4 g = g_geom[hit]; sphere_hit_point(o, d, closest, g.x, g.y, g.z, g.w, p, nn); }
+    w[0] = (float)hit; w[1] = (hit >= 0) ? closest : 0.f; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1370,6 +1488,11 @@ struct ptgpu_ctx {
     float *d_inv_radius = nullptr;
     float *d_ycy = nullptr;
     uint32_t shared_tests = 0; // spheres in shared-ordinate mask words (5-FMA filter test)
+    // sphere tree of the uploaded scene (tree_nodes = 0: none, the scan serves it)
+    TreeNode *d_tnodes = nullptr; float4 *d_tgeom = nullptr; uint32_t *d_tprim = nullptr;
+    uint32_t tree_root = 0, tree_nodes = 0, tree_depth = 0;
+    uint32_t tree_min_spheres = (uint32_t)kTile + 1u; // PT_LIMIT_TREE_MIN_SPHERES
+    int resident_tree[2] = {0, 0};                   // [det]: workgroups per CU of the tree variants
     bool have_camera = false;
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
@@ -1460,6 +1583,9 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1] = r;
+        for (int i = 0; i < 2; ++i) if (ctx->resident_tree[i] <= 0) ctx->resident_tree[i] = 1;
     }
     if (e != hipSuccess || !ctx->d_scratch) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -1479,7 +1605,7 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
 extern "C" int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PT_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    void *ptrs[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters, ctx->d_prim, ctx->d_lsph};
+    void *ptrs[] = {ctx->d_tnodes, ctx->d_tgeom, ctx->d_tprim, ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_part, ctx->d_stack, ctx->d_tmp, ctx->d_rec, ctx->d_counters, ctx->d_prim, ctx->d_lsph};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1513,6 +1639,13 @@ extern "C" int ptgpu_scene_info(const ptgpu_ctx *ctx, uint32_t *nspheres, uint32
     return PT_OK;
 }
 
+extern "C" int ptgpu_tree_info(const ptgpu_ctx *ctx, uint32_t *nodes, uint32_t *depth) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (nodes) *nodes = ctx->tree_nodes;
+    if (depth) *depth = ctx->tree_depth;
+    return PT_OK;
+}
+
 extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
     if (!ctx) return PT_ERR_BAD_ARG;
     switch (which) {
@@ -1526,6 +1659,10 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
     case PT_LIMIT_PRIMARY_BOUNCES:
         if (value < 1 || value > 2) return PT_ERR_BAD_ARG;
         ctx->primary_bounces = (uint32_t)value;
+        return PT_OK;
+    case PT_LIMIT_TREE_MIN_SPHERES:
+        if (value > 0xffffffffull) return PT_ERR_BAD_ARG;
+        ctx->tree_min_spheres = (uint32_t)value; // takes effect at the next ptgpu_set_scene
         return PT_OK;
     default: return PT_ERR_BAD_ARG;
     }
@@ -1550,6 +1687,74 @@ static float filter_threshold_of(float cx_, float cy_, float cz_, float radius) 
     return f;
 }
 static float filter_threshold(const pt_sphere &s) { return filter_threshold_of(s.cx, s.cy, s.cz, s.radius); }
+
+// The sphere tree (scene_is_hit_tree): top-down, split at the median centre along the axis the centres spread most,
+// leaves of <= kTreeLeaf spheres — balanced, so its depth is ceil(log2(n / kTreeLeaf)) + 1 whatever the scene.
+// Boxes hold centre +- |radius| rounded outwards.  Returns false (no tree: the scan serves the scene) for
+// non-finite spheres or a depth beyond the traversal stack.
+struct TreeBuild {
+    std::vector<TreeNode> nodes;
+    std::vector<float4> tgeom;
+    std::vector<uint32_t> tprim;
+    uint32_t root = 0, depth = 0;
+};
+struct TreeBox { float lo[3], hi[3]; };
+static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx, uint32_t b, uint32_t e, uint32_t level, TreeBuild &T, TreeBox &box) {
+    T.depth = std::max(T.depth, level);
+    for (int k = 0; k < 3; ++k) { box.lo[k] = INFINITY; box.hi[k] = -INFINITY; }
+    if (e - b <= kTreeLeaf) {
+        const uint32_t first = (uint32_t)T.tprim.size();
+        for (uint32_t i = b; i < e; ++i) {
+            const pt_sphere &s = sp[idx[i]];
+            const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
+            for (int k = 0; k < 3; ++k) {
+                box.lo[k] = std::min(box.lo[k], nextafterf(c[k] - r, -INFINITY));
+                box.hi[k] = std::max(box.hi[k], nextafterf(c[k] + r, INFINITY));
+            }
+            T.tgeom.push_back(make_float4(s.cx, s.cy, s.cz, s.radius));
+            T.tprim.push_back(idx[i]);
+        }
+        return kTreeLeafBit | ((e - b - 1u) << 29) | first;
+    }
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = b; i < e; ++i) {
+        const pt_sphere &s = sp[idx[i]];
+        const float c[3] = {s.cx, s.cy, s.cz};
+        for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]); }
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    const uint32_t mid = b + (e - b) / 2u;
+    std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](uint32_t x, uint32_t y) {
+        const float cx = axis == 0 ? sp[x].cx : axis == 1 ? sp[x].cy : sp[x].cz;
+        const float cy = axis == 0 ? sp[y].cx : axis == 1 ? sp[y].cy : sp[y].cz;
+        return cx < cy || (cx == cy && x < y);
+    });
+    const uint32_t me = (uint32_t)T.nodes.size();
+    T.nodes.emplace_back();
+    TreeBox b0, b1;
+    const uint32_t c0 = tree_build_range(sp, idx, b, mid, level + 1u, T, b0);
+    const uint32_t c1 = tree_build_range(sp, idx, mid, e, level + 1u, T, b1);
+    TreeNode &N = T.nodes[me];
+    N.a = make_float4(b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]);
+    N.b = make_float4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
+    N.c = make_float4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
+    N.ch = make_uint4(c0, c1, 0u, 0u);
+    for (int k = 0; k < 3; ++k) { box.lo[k] = std::min(b0.lo[k], b1.lo[k]); box.hi[k] = std::max(b0.hi[k], b1.hi[k]); }
+    return me;
+}
+static bool tree_build(const pt_sphere *sp, uint32_t n, TreeBuild &T) {
+    if (n > 0x1fffffffu) return false;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].radius)) return false;
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    T.nodes.reserve(n / 2u + 1u); T.tgeom.reserve(n); T.tprim.reserve(n);
+    TreeBox box;
+    T.root = tree_build_range(sp, idx, 0u, n, 1u, T, box);
+    if (T.nodes.empty()) T.nodes.emplace_back(); // a one-leaf scene: the root ref is the leaf, the node array is never read
+    return T.depth <= kTreeStack;
+}
 
 extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_t n) {
     if (!ctx || !spheres || n == 0) return PT_ERR_BAD_ARG;
@@ -1585,12 +1790,17 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     for (float &v : ycy) if (v != v) { const uint32_t q = 0x7fc00000u; memcpy(&v, &q, 4); } // the kernel compares these bits
     // Build the new tables aside and swap them in only when every step succeeded: a failure leaves the
     // context with its previous scene intact (never half-updated).
-    void *fresh[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const void *src[6] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data(), ycy.data()};
-    const size_t bytes[6] = {n_pad * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(uint32_t), n * sizeof(float),
-                             n_words * sizeof(float)};
+    TreeBuild tree;
+    const bool with_tree = ctx->tree_min_spheres != 0u && n >= ctx->tree_min_spheres && tree_build(spheres, n, tree);
+    constexpr int kTables = 9;
+    void *fresh[kTables] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void *src[kTables] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data(), ycy.data(), tree.nodes.data(), tree.tgeom.data(),
+                                tree.tprim.data()};
+    const size_t bytes[kTables] = {n_pad * sizeof(float4), n * sizeof(float4), n * sizeof(float4), n * sizeof(uint32_t), n * sizeof(float),
+                                   n_words * sizeof(float), tree.nodes.size() * sizeof(TreeNode), tree.tgeom.size() * sizeof(float4),
+                                   tree.tprim.size() * sizeof(uint32_t)};
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+    for (int i = 0; i < (with_tree ? kTables : 6) && e == hipSuccess; ++i) {
         e = hipMalloc(&fresh[i], bytes[i]);
         if (e == hipSuccess) e = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
     }
@@ -1599,7 +1809,11 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
         ctx->last_hip = (int)e;
         return (e == hipErrorOutOfMemory) ? PT_ERR_OOM : PT_ERR_HIP;
     }
-    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy};
+    void *olds[] = {ctx->d_filt, ctx->d_geom, ctx->d_mat, ctx->d_kind, ctx->d_inv_radius, ctx->d_ycy, ctx->d_tnodes, ctx->d_tgeom, ctx->d_tprim};
+    ctx->d_tnodes = (TreeNode *)fresh[6]; ctx->d_tgeom = (float4 *)fresh[7]; ctx->d_tprim = (uint32_t *)fresh[8];
+    ctx->tree_root = with_tree ? tree.root : 0u;
+    ctx->tree_nodes = with_tree ? (uint32_t)tree.nodes.size() : 0u;
+    ctx->tree_depth = with_tree ? tree.depth : 0u;
     ctx->d_filt = (float4 *)fresh[0]; ctx->d_geom = (float4 *)fresh[1]; ctx->d_mat = (float4 *)fresh[2];
     ctx->d_kind = (uint32_t *)fresh[3]; ctx->d_inv_radius = (float *)fresh[4]; ctx->d_ycy = (float *)fresh[5];
     ctx->nspheres = n;
@@ -1687,6 +1901,11 @@ struct Workspace {
 
 template <bool PRIMARY>
 static void launch_megakernel_p(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+    if (P.tnodes) {
+        if (det) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        return;
+    }
     if (det) {
         if (multi) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
         else hipLaunchKernelGGL((pt_megakernel<true, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
@@ -1723,10 +1942,11 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     if (npix == 0 || s1 == s0) return PT_OK;
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
 
-    const bool multi = ctx->n_pad > (uint32_t)kTile;
+    const bool tree = ctx->tree_nodes != 0u;
+    const bool multi = tree || ctx->n_pad > (uint32_t)kTile; // (the tree variants read the sphere tables from global memory, like multi-tile scenes)
     const bool det = cfg->mode == 1;
     // persistent grid: as many workgroups per CU as the kernel variant can keep resident
-    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : ctx->resident[det ? 1 : 0][multi ? 1 : 0];
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : tree ? ctx->resident_tree[det ? 1 : 0] : ctx->resident[det ? 1 : 0][multi ? 1 : 0];
     const uint32_t grid = (uint32_t)(ctx->compute_units * bpc);
     const uint32_t total_threads = grid * kBlock;
     const size_t stack_need = (size_t)(cfg->rebounds ? cfg->rebounds : 1u) * total_threads * sizeof(uint32_t);
@@ -1811,6 +2031,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
+    P.tnodes = tree ? ctx->d_tnodes : nullptr; P.tgeom = ctx->d_tgeom; P.tprim = ctx->d_tprim; P.troot = ctx->tree_root;
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
@@ -2017,10 +2238,12 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_LERP: in_stride = 9; out_stride = 4; break;
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
     case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 3; break;
+    case PT_FN_SCENE_HIT_TREE: in_stride = 6; out_stride = 8; break;
     default: return PT_ERR_UNSUPPORTED;
     }
     if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
     if (fn == PT_FN_CAST_RAY && !ctx->have_camera) return PT_ERR_BAD_ARG;
+    if (fn == PT_FN_SCENE_HIT_TREE && ctx->tree_nodes == 0u) return PT_ERR_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *d_in = nullptr, *d_out = nullptr, *d_thr = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_in, in_stride * n * sizeof(float)));
@@ -2038,6 +2261,10 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
         Cam cam = ctx->have_camera ? ctx->cam : Cam();
         if (fn == PT_FN_FILTER_BIT) {
             hipLaunchKernelGGL(pt_debug_filter_bit, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, (const float *)d_in, (const float *)d_thr, d_out, n);
+        } else if (fn == PT_FN_SCENE_HIT_TREE) {
+            hipLaunchKernelGGL(pt_debug_scene_hit_tree, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                               (const TreeNode *)ctx->d_tnodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->tree_root,
+                               (const float4 *)ctx->d_geom, t_min, t_max);
         } else if (fn == PT_FN_SCENE_HIT_FILTERED) {
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)

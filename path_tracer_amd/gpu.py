@@ -119,6 +119,12 @@ class GpuContext:
         check(self._L.ptgpu_scene_info(self._h, C.byref(n), C.byref(shared)), "ptgpu_scene_info")
         return {"nspheres": n.value, "shared_ordinate_tests": shared.value}
 
+    def tree_info(self):
+        """inner nodes (0: the uploaded scene is traced by the scan) and depth of the scene's sphere tree"""
+        nodes, depth = C.c_uint32(), C.c_uint32()
+        check(self._L.ptgpu_tree_info(self._h, C.byref(nodes), C.byref(depth)), "ptgpu_tree_info")
+        return {"nodes": nodes.value, "depth": depth.value}
+
     def device_info(self):
         cu, khz = C.c_int(), C.c_int()
         arch = C.create_string_buffer(64)

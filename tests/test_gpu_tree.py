@@ -1,0 +1,195 @@
+"""The sphere tree of large scenes (scene_is_hit_tree) against the scan over all spheres.
+
+scene.zig:96-110 tests every sphere for every ray.  With PT_LIMIT_TREE_MIN_SPHERES = 0 the megakernel does exactly that
+(conservative LDS filter + exact pass); with a tree it walks boxes and gives the exact Sphere.is_hit only to the spheres
+of the leaves it reaches.  Both must return the same closest hit for every ray — index and t, bit for bit — and so the
+same frames, path and ray counts.  PT_FN_SCENE_HIT is the plain ascending scan with strict '<' on the GPU (pinned
+against the oracle in test_gpu_functions.py); PT_FN_SCENE_HIT_TREE the tree walk on the same rays.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_scene(gpu, spheres, min_spheres):
+    from path_tracer_amd import _lib
+    gpu.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, min_spheres)
+    try:
+        gpu.set_scene(spheres)
+    finally:
+        gpu.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, _lib.PT_TREE_MIN_SPHERES_DEFAULT)
+
+
+def _rays(rng, spheres, n):
+    """origins on sphere surfaces, near them, far away and at the centres; directions random, axis-aligned (zero components),
+    aimed at sphere centres and grazing (aimed at a point one radius off a centre); some not normalised"""
+    c = np.stack([spheres["cx"], spheres["cy"], spheres["cz"]], axis=1).astype(np.float64)
+    r = np.abs(spheres["radius"].astype(np.float64))
+    pick = rng.integers(0, len(spheres), n)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    kind = rng.integers(0, 5, n)
+    o = np.where((kind == 0)[:, None], c[pick] + u * r[pick, None],                       # on a surface
+        np.where((kind == 1)[:, None], c[pick] + u * r[pick, None] * rng.uniform(1.0, 3.0, (n, 1)),
+        np.where((kind == 2)[:, None], rng.normal(0, 30, (n, 3)),
+        np.where((kind == 3)[:, None], c[pick], rng.normal(0, 3, (n, 3))))))
+    target = rng.integers(0, len(spheres), n)
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    dk = rng.integers(0, 5, n)
+    to_c = c[target] - o
+    graze = c[target] + v * r[target, None] * rng.choice([0.999, 1.0, 1.001], (n, 1)) - o
+    axis = np.zeros((n, 3)); axis[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    d = np.where((dk == 0)[:, None], v, np.where((dk == 1)[:, None], to_c, np.where((dk == 2)[:, None], graze,
+        np.where((dk == 3)[:, None], axis, v * rng.choice([1e-3, 0.5, 7.0], (n, 1))))))
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    unit = (rng.random((n, 1)) < 0.7) & (nrm > 0)
+    d = np.where(unit, d / np.where(nrm > 0, nrm, 1.0), d)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def _compare_hits(gpu, rays, t_min, t_max):
+    from path_tracer_amd import _lib
+    scan = gpu.debug_eval(_lib.PT_FN_SCENE_HIT, rays, t_min, t_max)
+    tree = gpu.debug_eval(_lib.PT_FN_SCENE_HIT_TREE, rays, t_min, t_max)
+    np.testing.assert_array_equal(tree.view(np.uint32), scan.view(np.uint32))
+    return scan
+
+
+def test_tree_is_built_for_large_scenes_only(gpu):
+    from path_tracer_amd import _lib, host
+    gpu.set_scene(host.Scene().setupScene(456, 21).spheres)                 # 488 spheres: one LDS tile
+    assert gpu.tree_info() == {"nodes": 0, "depth": 0}
+    with pytest.raises(Exception):
+        gpu.debug_eval(_lib.PT_FN_SCENE_HIT_TREE, np.zeros((1, 6), np.float32))
+    big = host.Scene().sceneSynthetic(3000, 7).spheres
+    gpu.set_scene(big)
+    info = gpu.tree_info()
+    assert 3000 // 4 - 1 <= info["nodes"] < 3000 and info["depth"] == 11   # ceil(log2(3000 / 4)) + 1
+    _set_scene(gpu, big, 0)
+    assert gpu.tree_info()["nodes"] == 0
+    _set_scene(gpu, big[:3], 1)                                             # a scene that is one leaf
+    assert gpu.tree_info() == {"nodes": 1, "depth": 1}
+    bad = big.copy(); bad["cx"][17] = np.nan                                # non-finite spheres keep the scan
+    gpu.set_scene(bad)
+    assert gpu.tree_info()["nodes"] == 0
+
+
+@pytest.mark.parametrize("n_scene", [18, 19, 20, 21])
+def test_closest_hits_of_the_reference_scenes(gpu, n_scene):
+    from path_tracer_amd import host
+    sp = host.Scene().setupScene(456, n_scene).spheres
+    _set_scene(gpu, sp, 1)
+    rng = np.random.default_rng(n_scene)
+    for t_min, t_max in ((0.1, 1000.0), (0.001, 1.0e6), (0.0, 50.0), (-5.0, 1000.0)):
+        scan = _compare_hits(gpu, _rays(rng, sp, 60000), t_min, t_max)
+        assert 0.1 < np.mean(scan[:, 0] >= 0) < 1.0
+
+
+def test_closest_hits_of_adversarial_scenes(gpu):
+    """radii from 1e-3 to 5000 and negative, coincident spheres (the lower index must win), concentric shells, a scene far
+    from the origin (coordinates ~1e4), everything on one point (the median split has nothing to split on)"""
+    from path_tracer_amd import _lib
+    rng = np.random.default_rng(5)
+    hits = 0
+    for trial in range(40):
+        n = int(rng.choice([2, 5, 40, 300, 2500]))
+        sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
+        spread = float(rng.choice([0.0, 4.0, 15.0, 60.0]))
+        off = float(rng.choice([0.0, 0.0, 1.0e4]))
+        sp["cx"], sp["cy"], sp["cz"] = off + rng.normal(0, spread, n), rng.normal(0, spread, n), rng.normal(0, spread, n) - off
+        sp["radius"] = rng.choice([1e-3, 0.02, 0.2, 0.5, 3.0, 40.0, -0.7], n)
+        sp["kind"] = 0
+        if trial % 3 == 0:
+            sp[0] = (0, -5000, 0, 5000, 0, 0.5, 0.5, 0.5, 0)
+        if n > 5:
+            sp[2] = sp[n - 1] = sp[n // 2]                                  # coincident triples, far apart in index
+            for f in ("cx", "cy", "cz"):
+                sp[f][4] = sp[f][3]                                         # concentric shells
+            sp["radius"][4] = 2.0 * abs(sp["radius"][3])
+        _set_scene(gpu, sp, 1)
+        assert gpu.tree_info()["nodes"] >= 1
+        for t_min, t_max in ((0.001, 1.0e6), (-2.0, 100.0)):
+            scan = _compare_hits(gpu, _rays(rng, sp, 30000), t_min, t_max)
+            hits += int(np.sum(scan[:, 0] >= 0))
+    assert hits > 100000
+
+
+def test_non_finite_rays_hit_nothing_either_way(gpu):
+    from path_tracer_amd import host
+    sp = host.Scene().sceneSynthetic(1000, 3).spheres
+    gpu.set_scene(sp)
+    assert gpu.tree_info()["nodes"] > 0
+    rays = np.zeros((8, 6), np.float32)
+    rays[:, 3:] = [[np.nan, 1, 0], [0, 0, 0], [np.inf, 0, 0], [1, np.nan, np.nan], [0, -np.inf, 1], [np.nan] * 3, [0, 1, 0], [1e-40, 1, 0]]
+    rays[5, :3] = np.nan
+    _compare_hits(gpu, rays, 0.001, 1.0e6)
+
+
+def _render_both(gpu, spheres, cfg, primary):
+    from path_tracer_amd import _lib
+    out = []
+    try:
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT if primary else 0)
+        for min_spheres in (1, 0):
+            _set_scene(gpu, spheres, min_spheres)
+            assert (gpu.tree_info()["nodes"] > 0) == (min_spheres == 1)
+            frame = gpu.render_sum(cfg, allow_not_unit=True)
+            st = gpu.stats()
+            out.append((frame, (st.paths, st.rays, st.not_unit, st.primary_rays, st.list2_rays)))
+    finally:
+        gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT)
+    (tree, st_tree), (scan, st_scan) = out
+    assert st_tree == st_scan
+    np.testing.assert_array_equal(tree, scan)
+    return tree
+
+
+@pytest.mark.parametrize("primary", [True, False])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_frames_tree_against_scan(gpu, primary, deterministic):
+    """one-tile scenes forced through the tree, and many-tile scenes forced through the scan: same frames, same counts"""
+    from path_tracer_amd import host
+    img = host.Image(96)
+    rt = host.RayTracerConfig(subpixels=2, rays_per_subsample=6, rebounds=50)
+    for n_scene in (19, 21):
+        gpu.set_camera(host.Camera.preset(n_scene).pod)
+        _render_both(gpu, host.Scene().setupScene(456, n_scene).spheres, host.make_pt_config(img, rt, seed=3, chunk=4, deterministic=deterministic), primary)
+    gpu.set_camera(host.Camera.preset(21).pod)
+    for n, seed in ((600, 1), (3000, 7)):
+        _render_both(gpu, host.Scene().sceneSynthetic(n, seed).spheres, host.make_pt_config(img, rt, seed=4, chunk=4, deterministic=deterministic), primary)
+
+
+def test_frames_tree_against_scan_odd_cases(gpu):
+    """negative t_min (hits behind the origin count), first-hit colour functions, rebounds 0, tiles and ranges"""
+    from path_tracer_amd import host
+    sp = host.Scene().sceneSynthetic(1500, 2).spheres
+    gpu.set_camera(host.Camera.preset(21).pod)
+    img = host.Image(80)
+    _render_both(gpu, sp, host.make_pt_config(img, host.RayTracerConfig(subpixels=2, rays_per_subsample=3, t_min=-5.0, t_max=1000.0, rebounds=6), seed=2), True)
+    rt = host.RayTracerConfig(subpixels=2, rays_per_subsample=4, rebounds=12)
+    for kw in (dict(chunk=4, illumination=1), dict(chunk=4, illumination=2), dict(chunk=3, istart=333, istop=2999),
+               dict(chunk=4, tile_pixels=256, tile_count=3, tile_index=1), dict(chunk=0)):
+        _render_both(gpu, sp, host.make_pt_config(img, rt, seed=8, **kw), True)
+    _render_both(gpu, sp, host.make_pt_config(img, host.RayTracerConfig(subpixels=2, rays_per_subsample=4, rebounds=0), seed=8, chunk=4), True)
+
+
+def test_tree_frame_against_the_oracle(orc, gpu):
+    """and directly against the CPU restatement of the reference's scan"""
+    import ctypes as C
+    from path_tracer_amd import host
+    scene = host.Scene().sceneSynthetic(2000, 11)
+    cam = host.Camera.preset(21)
+    gpu.set_scene(scene.spheres)
+    assert gpu.tree_info()["nodes"] > 0
+    gpu.set_camera(cam.pod)
+    img = host.Image(64)
+    rt = host.RayTracerConfig(subpixels=2, rays_per_subsample=4, rebounds=50)
+    cfg = host.make_pt_config(img, rt, seed=6, chunk=4)
+    got = gpu.render_sum(cfg)
+    ocfg = orc.Config()
+    C.memmove(C.byref(ocfg), C.byref(cfg), C.sizeof(ocfg))
+    ocam = orc.Camera()
+    C.memmove(C.byref(ocam), C.byref(cam.pod), C.sizeof(ocam))
+    rc, ref, _ = orc.render_sum(scene.spheres, ocam, ocfg, nthreads=4)
+    assert rc == 0
+    np.testing.assert_array_equal(got, ref)

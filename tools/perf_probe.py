@@ -23,7 +23,11 @@ def main():
     cfg = host.make_pt_config(img, host.RayTracerConfig(subpixels=4, rays_per_subsample=spp, rebounds=depth), seed=456, chunk=chunk, **tkw)
     g = GpuContext(0)
     info = g.device_info()
-    g.set_scene(sp); g.set_camera(cam)
+    if "PROBE_TREE_MIN" in os.environ:  # 0: scan whatever the size; 1: sphere tree whatever the size
+        from path_tracer_amd import _lib
+        g.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, int(os.environ["PROBE_TREE_MIN"]))
+    t = time.time(); g.set_scene(sp); g.set_camera(cam)
+    print("set_scene %.1f ms, tree %s" % ((time.time() - t) * 1e3, g.tree_info()))
     if "PROBE_PRIMARY_BYTES" in os.environ:  # 0: camera rays inside the megakernel
         from path_tracer_amd import _lib
         g.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, int(float(os.environ["PROBE_PRIMARY_BYTES"])))
