@@ -422,6 +422,9 @@ __device__ __forceinline__ void scene_is_hit_tree(const TreeNode *__restrict__ n
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     // (a lane without a ray stays out: its parked NaN direction would pass every box — min/max drop NaN operands)
     uint32_t cur = active ? root : kTreeNone, sp = 0;
+    // One loop, both bodies: a lane holding a leaf tests its spheres in the same iteration in which others test boxes.
+    // (Measured against "while-while" — inner nodes until every lane holds a leaf, then the leaves together: 63 vs 75 ms on
+    // the 100 000-sphere scene, 43.5 vs 43.1 on 3 000 spheres, 30.2 vs 29.0 on scene 21 forced through the tree.)
     for (;;) {
         if (cur == kTreeNone && sp > 0u) cur = s_stack[--sp * kBlock + tid];
         if (__ballot(cur != kTreeNone) == 0ull) break;
@@ -852,14 +855,47 @@ __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float
     out[j] = S;
 }
 
+// One lane's walk of the sphere tree for the list kernel: box_ok(lo, hi) says whether a box can hold a sphere the
+// list wants, leaf(slot) looks at the sphere in leaf slot `slot` and returns false to end the walk (the list has
+// overflowed).  (Lanes walk independently: no wave-level operation inside; neighbouring pixels take nearly the same way.)
+template <class BoxOk, class Leaf>
+__device__ __forceinline__ void list_tree_walk(const TreeNode *__restrict__ nodes, uint32_t root, uint32_t *s_stack, uint32_t tid, bool active, BoxOk box_ok,
+                                               Leaf leaf) {
+    uint32_t cur = active ? root : kTreeNone, sp = 0;
+    while (cur != kTreeNone) {
+        if (cur & kTreeLeafBit) {
+            const uint32_t first = cur & 0x1fffffffu, cnt = ((cur >> 29) & 3u) + 1u;
+            bool go_on = true;
+            for (uint32_t k = 0; k < cnt; ++k) go_on = leaf(first + k) && go_on;
+            cur = (go_on && sp > 0u) ? s_stack[--sp * 256u + tid] : kTreeNone;
+        } else {
+            const TreeNode *nd = nodes + cur;
+            const float4 A = nd->a, B = nd->b, Cc = nd->c;
+            const uint4 ch = nd->ch;
+            const bool h0 = box_ok(A.x, A.y, A.z, A.w, B.x, B.y);
+            const bool h1 = box_ok(B.z, B.w, Cc.x, Cc.y, Cc.z, Cc.w);
+            if (h0 && h1) { s_stack[sp++ * 256u + tid] = ch.y; cur = ch.x; }
+            else if (h0 || h1) cur = h0 ? ch.x : ch.y;
+            else cur = sp > 0u ? s_stack[--sp * 256u + tid] : kTreeNone;
+        }
+    }
+}
+
+// TREE: the two passes over the spheres walk the scene's sphere tree instead (large scenes): a box is entered when the
+// ball around it — centre bc, radius hd + the largest r' - r of a sphere inside — passes the very test its spheres take
+// (a sphere inside the box lies inside that ball, and both tests only get easier for a larger ball around the same
+// points), so the lists hold the same spheres, in walk order instead of ascending (pt_primary's tie rule covers that).
+template <bool TREE>
 __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_t width, uint32_t height, uint32_t slot0, uint32_t npix,
                                                         uint32_t idx_start, uint32_t idx_stop, uint32_t tile_pixels, uint32_t tile_count,
                                                         uint32_t tile_index, const ListSphere *__restrict__ sph, uint32_t nspheres,
                                                         const uint32_t *__restrict__ kind, const float4 *__restrict__ mat, float t_min,
-                                                        uint32_t second_bounce, uint32_t *__restrict__ lists) {
+                                                        uint32_t second_bounce, uint32_t *__restrict__ lists, const TreeNode *__restrict__ tnodes,
+                                                        const uint32_t *__restrict__ tprim, uint32_t troot) {
     // The per-sphere table goes through LDS in tiles (broadcast reads): read straight from memory the loops below were
     // bound by the latency of one scalar load per sphere at three waves per SIMD.
-    __shared__ ListSphere s_sph[kListTile];
+    __shared__ ListSphere s_sph[TREE ? 1 : kListTile];
+    __shared__ uint32_t s_stack[TREE ? kTreeStack * 256 : 1];
     const uint32_t po = blockIdx.x * 256u + threadIdx.x;
     bool act = po < npix;                      // this thread still builds list A
     uint32_t *L = lists + (size_t)(act ? po : 0u) * kListStride;
@@ -889,7 +925,45 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-5f) / lenD : 0.0f;
     const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f);
     uint32_t count = 0;
-    for (uint32_t t0 = 0; t0 < nspheres; t0 += kListTile) {
+    // the ball around a box, relative to the camera: x = bc - O, |x|^2, radius hd (rounded up)
+    auto box_ball = [&](float lx, float ly, float lz, float hx, float hy, float hz, double x[3], double &xx, double &hd) {
+        x[0] = 0.5 * ((double)lx + (double)hx) - C.O[0]; x[1] = 0.5 * ((double)ly + (double)hy) - C.O[1]; x[2] = 0.5 * ((double)lz + (double)hz) - C.O[2];
+        xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        const double ex = (double)hx - (double)lx, ey = (double)hy - (double)ly, ez = (double)hz - (double)lz;
+        hd = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-12);
+    };
+    if (TREE) {
+        list_tree_walk(tnodes, troot, s_stack, threadIdx.x, act,
+            [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+                double x[3], xx, hd;
+                box_ball(lx, ly, lz, hx, hy, hz, x, xx, hd);
+                const double xl = sqrt(xx) + hd + C.Rl;                                // >= |c - O| + Rl of every sphere inside
+                double R = hd + sqrt(kListGamma * (2.0 * xl * xl + hd * hd)) * (1.0 + 1e-9); // >= hd - r + r' of each of them (pt_list_prep's r')
+                // list_piece lets a sphere in that is outside by up to its tolerance (1e-9 relative in squared distance, < 1e-4 (|x| + R)
+                // in distance): the ball takes that much more, so its own tolerance never matters
+                R += 1e-4 * (xl + R + fabs(a1) + fabs(a2));
+                const double xd = x[0] * Dv[0] + x[1] * Dv[1] + x[2] * Dv[2];
+                if (lenD > 0.0f) { // the spheres' quick reject (below), for the ball: its centre is too far from the central line
+                    const float base = (float)R * (1.0f + 1e-6f) + a1f;
+                    const float tau_hi = ((float)xl * (1.0f + 1e-6f) + base) * inv_lenD;
+                    const float Rmax = (base + b2f * tau_hi) * (1.0f + 1e-5f);
+                    if (xx - xd * xd * invDD > (double)Rmax * (double)Rmax) return false;
+                }
+                return list_piece(DD, xx, xd, R + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, R + a2, b2, 1.0, 1e300);
+            },
+            [&](uint32_t slot) {
+                const uint32_t j = tprim[slot];
+                const ListSphere &S = sph[j];
+                const double xx = S.xx;
+                const double xd = S.x[0] * Dv[0] + S.x[1] * Dv[1] + S.x[2] * Dv[2];
+                if (list_piece(DD, xx, xd, S.reff + a1, b1, 0.0, 1.0) || list_piece(DD, xx, xd, S.reff + a2, b2, 1.0, 1e300)) {
+                    if (count < kListCap) L[count] = j;
+                    count++;
+                }
+                return count <= kListCap; // one too many: the pixel's camera rays take the megakernel's walk, no need to count on
+            });
+    }
+    for (uint32_t t0 = 0; !TREE && t0 < nspheres; t0 += kListTile) {
         const uint32_t tn = min(kListTile, nspheres - t0);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < tn; i += 256u) s_sph[i] = sph[t0 + i];
@@ -1045,7 +1119,7 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         Sj = order[ic];
     }
     doB = doB && Sj != kListEnd;
-    if (!__syncthreads_or(doB ? 1 : 0)) return;   // nobody in this workgroup: skip the second pass over the spheres
+    if (!TREE && !__syncthreads_or(doB ? 1 : 0)) return;   // nobody in this workgroup: skip the second pass over the spheres
     uint32_t *B = L + kListB;
     uint32_t cnt2 = 0;
     // The condition, (y.a) >= cosA sqrt(|y|^2 - R^2) - sinA R with y = c_j - p0 and R = r' + rho_p, is evaluated in f32
@@ -1056,7 +1130,48 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     tdl = __builtin_amdgcn_sqrtf(tdl) * (1.0f + 1e-6f);
     const float cosAf = (float)cosA * (1.0f - 1e-5f) - 1e-5f, sinAf = (float)sinA * (1.0f + 1e-5f) + 1e-5f;
     const float rho_pf = (float)rho_p * (1.0f + 1e-6f), gammaf = (float)kListGamma * (1.0f + 1e-6f);
-    for (uint32_t t0 = 0; t0 < nspheres; t0 += kListTile) {
+    // sphere j against the cone; true = on the list
+    auto cone_sphere = [&](const ListSphere &S) -> bool {
+        const float yf0 = S.xf[0] - tdf[0], yf1 = S.xf[1] - tdf[1], yf2 = S.xf[2] - tdf[2];
+        const float err = 1e-6f * (S.xl + tdl);              // >= the error of yf (inputs rounded to f32, three subtractions)
+        const float yl = __builtin_amdgcn_sqrtf(yf0 * yf0 + yf1 * yf1 + yf2 * yf2);
+        const float ylu = yl * (1.0f + 1e-6f) + err + rho_pf;
+        const float Rf = (fabsf(S.r) + __builtin_amdgcn_sqrtf(gammaf * (2.0f * ylu * ylu + S.r * S.r)) + rho_pf) * (1.0f + 1e-5f) + err;
+        if (yl > Rf) {
+            const float ya = yf0 * axf[0] + yf1 * axf[1] + yf2 * axf[2] + err + 1e-6f * yl;
+            const float yll = fmaxf(yl * (1.0f - 1e-6f) - err, 0.0f);
+            const float rhs = cosAf * __builtin_amdgcn_sqrtf(fmaxf(yll * yll - Rf * Rf, 0.0f)) * (1.0f - 1e-5f) - sinAf * Rf;
+            if (ya < rhs - 1e-5f * (yl + Rf)) return false;
+        }
+        return true;
+    };
+    if (TREE) {
+        // the ball of a box against the cone, in double with the same permissive bounds: radius hd + (r' - r) + rho_p + what the f32 test
+        // above may add to a sphere's radius (1e-5 relative + err), so that a sphere that test lets in always finds its boxes open
+        const double cosAd = (double)cosAf, sinAd = (double)sinAf;
+        list_tree_walk(tnodes, troot, s_stack, threadIdx.x, doB,
+            [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+                double x[3], xx, hd;
+                box_ball(lx, ly, lz, hx, hy, hz, x, xx, hd);
+                double y[3], yy = 0.0, ya = 0.0;
+                for (int i = 0; i < 3; ++i) { y[i] = x[i] - tau0 * Dv[i]; yy += y[i] * y[i]; ya += y[i] * ax[i]; }
+                const double yl = sqrt(yy), ylu = yl + hd + rho_p;
+                const double err = 2e-6 * (sqrt(xx) + hd + (double)tdl);
+                const double R = (hd + sqrt(kListGamma * 1.001 * (2.0 * ylu * ylu + hd * hd)) + rho_p) * (1.0 + 3e-5) + 2.0 * err;
+                if (!(yl > R)) return true;
+                const double rhs = cosAd * sqrt(fmax(yy - R * R, 0.0)) * (1.0 - 1e-5) - sinAd * R;
+                return !(ya + 1e-4 * yl + 1e-5 * (yl + R) < rhs); // (1e-4: more than the permissive terms of the sphere test can differ between a sphere and its box)
+            },
+            [&](uint32_t slot) {
+                const uint32_t j = tprim[slot];
+                if (cone_sphere(sph[j])) {
+                    if (cnt2 < kListCapB) B[cnt2] = j;
+                    cnt2++;
+                }
+                return cnt2 <= kListCapB;
+            });
+    }
+    for (uint32_t t0 = 0; !TREE && t0 < nspheres; t0 += kListTile) {
         const uint32_t tn = min(kListTile, nspheres - t0);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < tn; i += 256u) s_sph[i] = sph[t0 + i];
@@ -1064,18 +1179,7 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         if (!doB) continue;
 #pragma unroll 4
         for (uint32_t jj = 0; jj < tn; ++jj) {
-            const ListSphere &S = s_sph[jj];
-            const float yf0 = S.xf[0] - tdf[0], yf1 = S.xf[1] - tdf[1], yf2 = S.xf[2] - tdf[2];
-            const float err = 1e-6f * (S.xl + tdl);              // >= the error of yf (inputs rounded to f32, three subtractions)
-            const float yl = __builtin_amdgcn_sqrtf(yf0 * yf0 + yf1 * yf1 + yf2 * yf2);
-            const float ylu = yl * (1.0f + 1e-6f) + err + rho_pf;
-            const float Rf = (fabsf(S.r) + __builtin_amdgcn_sqrtf(gammaf * (2.0f * ylu * ylu + S.r * S.r)) + rho_pf) * (1.0f + 1e-5f) + err;
-            if (yl > Rf) {
-                const float ya = yf0 * axf[0] + yf1 * axf[1] + yf2 * axf[2] + err + 1e-6f * yl;
-                const float yll = fmaxf(yl * (1.0f - 1e-6f) - err, 0.0f);
-                const float rhs = cosAf * __builtin_amdgcn_sqrtf(fmaxf(yll * yll - Rf * Rf, 0.0f)) * (1.0f - 1e-5f) - sinAf * Rf;
-                if (ya < rhs - 1e-5f * (yl + Rf)) continue;
-            }
+            if (!cone_sphere(s_sph[jj])) continue;
             if (cnt2 < kListCapB) B[cnt2] = t0 + jj;
             cnt2++;
         }
@@ -1167,7 +1271,9 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                             cands++;
                             float t;
                             if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) {
-                                if (t < closest) { closest = t; hit = (int)j; }
+                                // lists built by a tree walk (large scenes) are in no particular order: among equal t the lower index
+                                // wins explicitly, which is what the ascending order gives the strict '<' for free
+                                if (t < closest || (MULTI_TILE && t == closest && (int)j < hit)) { closest = t; hit = (int)j; }
                             }
                         }
                     }
@@ -1688,48 +1794,94 @@ static float filter_threshold_of(float cx_, float cy_, float cz_, float radius) 
 }
 static float filter_threshold(const pt_sphere &s) { return filter_threshold_of(s.cx, s.cy, s.cz, s.radius); }
 
-// The sphere tree (scene_is_hit_tree): top-down, split at the median centre along the axis the centres spread most,
-// leaves of <= kTreeLeaf spheres — balanced, so its depth is ceil(log2(n / kTreeLeaf)) + 1 whatever the scene.
-// Boxes hold centre +- |radius| rounded outwards.  Returns false (no tree: the scan serves the scene) for
-// non-finite spheres or a depth beyond the traversal stack.
+// The sphere tree (scene_is_hit_tree), built top-down.  A range of spheres is split where the surface-area
+// heuristic is cheapest — area(left box) x count(left) + area(right box) x count(right), evaluated at 15 bin
+// boundaries per axis over the centres (a ground sphere of radius 1000 among small ones ends up alone near the
+// root instead of inflating every box on its side) — as long as the larger part can still be finished by median
+// splits within the traversal stack; otherwise, and when the heuristic finds nothing to separate (coincident
+// centres), at the median centre along the widest axis.  Leaves of <= kTreeLeaf spheres.  Boxes hold
+// centre +- |radius| rounded outwards.  Returns false (no tree: the scan serves the scene) for non-finite spheres
+// or a depth beyond the traversal stack.
 struct TreeBuild {
     std::vector<TreeNode> nodes;
     std::vector<float4> tgeom;
     std::vector<uint32_t> tprim;
     uint32_t root = 0, depth = 0;
 };
-struct TreeBox { float lo[3], hi[3]; };
+struct TreeBox {
+    float lo[3], hi[3];
+    void clear() { for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+    void add(const TreeBox &o) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); } }
+    double area() const {
+        const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        return (x < 0.0) ? 0.0 : x * y + y * z + z * x;
+    }
+};
+static TreeBox tree_sphere_box(const pt_sphere &s) {
+    TreeBox b;
+    const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
+    for (int k = 0; k < 3; ++k) { b.lo[k] = nextafterf(c[k] - r, -INFINITY); b.hi[k] = nextafterf(c[k] + r, INFINITY); }
+    return b;
+}
+static uint32_t tree_levels_of_median_split(uint32_t count) { // levels (leaf level included) a balanced subtree of `count` spheres takes
+    uint32_t levels = 1;
+    while (count > kTreeLeaf) { count = (count + 1u) / 2u; ++levels; }
+    return levels;
+}
 static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx, uint32_t b, uint32_t e, uint32_t level, TreeBuild &T, TreeBox &box) {
     T.depth = std::max(T.depth, level);
-    for (int k = 0; k < 3; ++k) { box.lo[k] = INFINITY; box.hi[k] = -INFINITY; }
+    box.clear();
     if (e - b <= kTreeLeaf) {
         const uint32_t first = (uint32_t)T.tprim.size();
         for (uint32_t i = b; i < e; ++i) {
             const pt_sphere &s = sp[idx[i]];
-            const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
-            for (int k = 0; k < 3; ++k) {
-                box.lo[k] = std::min(box.lo[k], nextafterf(c[k] - r, -INFINITY));
-                box.hi[k] = std::max(box.hi[k], nextafterf(c[k] + r, INFINITY));
-            }
+            box.add(tree_sphere_box(s));
             T.tgeom.push_back(make_float4(s.cx, s.cy, s.cz, s.radius));
             T.tprim.push_back(idx[i]);
         }
         return kTreeLeafBit | ((e - b - 1u) << 29) | first;
     }
+    auto centre = [&](uint32_t i, int k) -> float { const pt_sphere &s = sp[i]; return k == 0 ? s.cx : k == 1 ? s.cy : s.cz; };
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = b; i < e; ++i) {
-        const pt_sphere &s = sp[idx[i]];
-        const float c[3] = {s.cx, s.cy, s.cz};
-        for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]); }
+    for (uint32_t i = b; i < e; ++i)
+        for (int k = 0; k < 3; ++k) { clo[k] = std::min(clo[k], centre(idx[i], k)); chi[k] = std::max(chi[k], centre(idx[i], k)); }
+    // binned surface-area heuristic
+    constexpr int kBins = 16;
+    double best_cost = INFINITY;
+    int best_axis = -1, best_bin = 0;
+    uint32_t best_left = 0;
+    auto bin_of = [&](uint32_t i, int k) -> int {
+        const double f = ((double)centre(i, k) - clo[k]) / ((double)chi[k] - clo[k]) * kBins;
+        return std::min(kBins - 1, std::max(0, (int)f));
+    };
+    for (int k = 0; k < 3; ++k) {
+        if (!(chi[k] > clo[k])) continue;
+        TreeBox bb[kBins]; uint32_t cnt[kBins] = {0};
+        for (int j = 0; j < kBins; ++j) bb[j].clear();
+        for (uint32_t i = b; i < e; ++i) { const int j = bin_of(idx[i], k); bb[j].add(tree_sphere_box(sp[idx[i]])); cnt[j]++; }
+        double right_area[kBins]; uint32_t right_cnt[kBins];
+        TreeBox acc; acc.clear(); uint32_t n = 0;
+        for (int j = kBins - 1; j > 0; --j) { acc.add(bb[j]); n += cnt[j]; right_area[j] = acc.area(); right_cnt[j] = n; }
+        acc.clear(); n = 0;
+        for (int j = 0; j + 1 < kBins; ++j) { // split between bins j and j + 1
+            acc.add(bb[j]); n += cnt[j];
+            if (n == 0u || right_cnt[j + 1] == 0u) continue;
+            const double cost = acc.area() * n + right_area[j + 1] * right_cnt[j + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; best_left = n; }
+        }
     }
-    int axis = 0;
-    for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-    const uint32_t mid = b + (e - b) / 2u;
-    std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](uint32_t x, uint32_t y) {
-        const float cx = axis == 0 ? sp[x].cx : axis == 1 ? sp[x].cy : sp[x].cz;
-        const float cy = axis == 0 ? sp[y].cx : axis == 1 ? sp[y].cy : sp[y].cz;
-        return cx < cy || (cx == cy && x < y);
-    });
+    uint32_t mid = b + (e - b) / 2u;
+    const uint32_t larger = std::max(best_left, (e - b) - best_left);
+    if (best_axis >= 0 && level + 1u + tree_levels_of_median_split(larger) <= kTreeStack) {
+        mid = (uint32_t)(std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t i) { return bin_of(i, best_axis) <= best_bin; }) - idx.begin());
+    } else {
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+        std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](uint32_t x, uint32_t y) {
+            const float cx = centre(x, axis), cy = centre(y, axis);
+            return cx < cy || (cx == cy && x < y);
+        });
+    }
     const uint32_t me = (uint32_t)T.nodes.size();
     T.nodes.emplace_back();
     TreeBox b0, b1;
@@ -1740,7 +1892,7 @@ static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx
     N.b = make_float4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
     N.c = make_float4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
     N.ch = make_uint4(c0, c1, 0u, 0u);
-    for (int k = 0; k < 3; ++k) { box.lo[k] = std::min(b0.lo[k], b1.lo[k]); box.hi[k] = std::max(b0.hi[k], b1.hi[k]); }
+    box.add(b0); box.add(b1);
     return me;
 }
 static bool tree_build(const pt_sphere *sp, uint32_t n, TreeBuild &T) {
@@ -2064,10 +2216,17 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg], stream));
             }
-            hipLaunchKernelGGL(pt_primary_lists, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
-                               cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
-                               ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min,
-                               (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u, d_lists);
+            const uint32_t second = (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u;
+            if (tree)
+                hipLaunchKernelGGL(pt_primary_lists<true>, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
+                                   cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
+                                   ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min, second, d_lists,
+                                   (const TreeNode *)ctx->d_tnodes, (const uint32_t *)ctx->d_tprim, ctx->tree_root);
+            else
+                hipLaunchKernelGGL(pt_primary_lists<false>, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
+                                   cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
+                                   ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min, second, d_lists,
+                                   (const TreeNode *)nullptr, (const uint32_t *)nullptr, 0u);
             HIP_TRY(ctx, hipGetLastError());
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
             const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);

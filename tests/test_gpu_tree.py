@@ -64,7 +64,7 @@ def test_tree_is_built_for_large_scenes_only(gpu):
     big = host.Scene().sceneSynthetic(3000, 7).spheres
     gpu.set_scene(big)
     info = gpu.tree_info()
-    assert 3000 // 4 - 1 <= info["nodes"] < 3000 and info["depth"] == 11   # ceil(log2(3000 / 4)) + 1
+    assert 3000 // 4 - 1 <= info["nodes"] < 3000 and 11 <= info["depth"] <= 24   # at best ceil(log2(3000 / 4)) + 1 levels, at most the stack
     _set_scene(gpu, big, 0)
     assert gpu.tree_info()["nodes"] == 0
     _set_scene(gpu, big[:3], 1)                                             # a scene that is one leaf
@@ -193,3 +193,51 @@ def test_tree_frame_against_the_oracle(orc, gpu):
     rc, ref, _ = orc.render_sum(scene.spheres, ocam, ocfg, nthreads=4)
     assert rc == 0
     np.testing.assert_array_equal(got, ref)
+
+
+def test_lists_built_by_the_tree_walk_random_cameras_and_adversarial_scenes(gpu):
+    """The primary pass of a tree scene builds its per-pixel lists by walking the tree (pt_primary_lists<true>): frames with
+    those lists + the tree megakernel against frames without the primary pass through the scan, over pinhole to very wide
+    lenses, cameras inside spheres, radii from 1e-3 to 5000 and negative, coincident spheres, dense scenes whose lists overflow."""
+    from path_tracer_amd import _lib, host
+    rng = np.random.default_rng(23)
+    img = host.Image(64)    # 64 x 36
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=8, t_min=0.001, t_max=1.0e6, rebounds=8)
+    listed = second = total = 0
+    for trial in range(48):
+        n = int(rng.choice([3, 40, 300, 1200]))
+        sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
+        spread = float(rng.choice([4.0, 15.0, 60.0]))
+        sp["cx"], sp["cy"], sp["cz"] = rng.normal(0, spread, n), rng.normal(0, spread, n), rng.normal(0, spread, n)
+        sp["radius"] = rng.choice([1e-3, 0.02, 0.2, 0.5, 3.0, 40.0, -0.7], n)
+        sp["kind"] = rng.choice([0, 1, 2], n, p=[0.6, 0.25, 0.15])
+        sp["ar"], sp["ag"], sp["ab"] = rng.random(n), rng.random(n), rng.random(n)
+        sp["param"] = np.where(sp["kind"] == 2, 1.5, 0.3 * rng.random(n))
+        sp[0] = (0, -5000, 0, 5000, 0, 0.5, 0.5, 0.5, 0)
+        if n > 3:
+            sp[1] = (2000, 0, 0, 1.0, 0, 1, 1, 1, 0)
+            sp[2] = sp[3] = (1, 1, 1, 0.25, 0, 1, 0.5, 0.2, 0)     # coincident: the lower index must win
+        lookfrom = rng.normal(0, 6, 3)
+        lookat = lookfrom + rng.normal(0, 1, 3) * rng.choice([0.5, 3.0, 20.0])
+        vup = np.array([0.0, 1.0, 0.0]) + rng.normal(0, 0.3, 3)
+        cam = host.Camera.new(lookfrom, lookat, vup, float(rng.choice([5.0, 20.0, 60.0, 120.0])), img.aspect_ratio,
+                              float(rng.choice([0.0, 0.0, 0.05, 0.5, 4.0])), float(rng.choice([0.3, 3.0, 10.0, 40.0])))
+        gpu.set_camera(cam.pod)
+        cfg = host.make_pt_config(img, rt, seed=300 + trial, chunk=16)
+        try:
+            _set_scene(gpu, sp, 1)
+            tree = gpu.render_sum(cfg, allow_not_unit=True)
+            st = gpu.stats()
+            gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 0)
+            _set_scene(gpu, sp, 0)
+            scan = gpu.render_sum(cfg, allow_not_unit=True)
+            st0 = gpu.stats()
+        finally:
+            gpu.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, _lib.PT_PRIMARY_BYTES_DEFAULT)
+        assert (st.paths, st.rays, st.not_unit) == (st0.paths, st0.rays, st0.not_unit) and st0.primary_rays == 0
+        np.testing.assert_array_equal(tree, scan)
+        listed += st.primary_rays
+        second += st.list2_rays
+        total += st.paths
+    assert 0.5 * total < listed < total     # listed pixels and overflowing ones
+    assert second > 0.02 * total            # second-bounce lists too
