@@ -151,13 +151,14 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, list2_rays, segments = [], [], 0, 0, 0, 0, 0, 0
+    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, list2_rays, segments, cands = [], [], 0, 0, 0, 0, 0, 0, 0
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st.kernel_ms)   # HIP events around the tracing kernels (primary pass + megakernel), on the stream they ran on
         primary_ms.append(st.primary_ms) # ... around the primary pass alone (0 when the render took several segments)
         paths += st.paths
         rays += st.rays
+        cands += st.candidates
         wave_steps += st.wave_steps
         primary_rays += st.primary_rays + st.list2_rays   # every ray the primary pass resolved against a per-pixel list
         list2_rays += st.list2_rays
@@ -183,6 +184,7 @@ def main():
         k_ms = sum(kernel_ms) / len(kernel_ms)
         p_ms = sum(primary_ms) / len(primary_ms)
         shared = gpu.scene_info()["shared_ordinate_tests"]
+        tree = gpu.tree_info()   # nodes > 0: Scene.is_hit walks the sphere tree (large scenes), and the filter-scan pricing of `executed_frac` does not apply
         paths_l, rays_l, prim_l = paths / args.steps, rays / args.steps, primary_rays / args.steps
         render_flops = algorithmic_flops(paths_l, rays_l, nsph)        # the reference's scan for EVERY ray of the render
         render = {"kernels": "pt_primary_lists + pt_primary + pt_megakernel" if prim_l else "pt_megakernel",
@@ -190,7 +192,7 @@ def main():
                   "paths": paths_l, "rays": rays_l, "primary_rays": prim_l, "of_which_second_bounce": list2_rays / args.steps,
                   "algorithmic_flops": render_flops,
                   "algorithmic_frac": render_flops / (k_ms * 1e-3) / PEAK_FP32_VALU,
-                  "executed_frac": executed_flops(paths_l, rays_l, nsph, shared, prim_l) / (k_ms * 1e-3) / PEAK_FP32_VALU}
+                  "executed_frac": None if tree["nodes"] else executed_flops(paths_l, rays_l, nsph, shared, prim_l) / (k_ms * 1e-3) / PEAK_FP32_VALU}
         # the dominant kernel: the megakernel over the rays IT scans (every ray when the primary pass is off)
         m_ms = k_ms - p_ms
         scan_rays = rays_l - prim_l
@@ -221,7 +223,9 @@ def main():
                          "rays_per_launch": scan_rays / max(segments, 1), "wave_steps_per_launch": wave_steps / args.steps / max(segments, 1),
                          "spheres": nsph, "shared_ordinate_tests": shared,
                          "basis": "algorithmic",
-                         "executed_frac": (scan_rays * ((nsph - shared) * 15.0 + shared * 11.0 + 60.0)) / (m_ms * 1e-3) / PEAK_FP32_VALU,
+                         "executed_frac": None if tree["nodes"] else (scan_rays * ((nsph - shared) * 15.0 + shared * 11.0 + 60.0)) / (m_ms * 1e-3) / PEAK_FP32_VALU,
+                         "scene_is_hit": ("sphere tree: %d inner nodes, %d levels, %.1f exact sphere tests per ray" % (tree["nodes"], tree["depth"], cands / max(rays, 1)))
+                                         if tree["nodes"] else "filter scan over all spheres + exact pass",
                          "render": render,
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d) of the dominant kernel, pt_megakernel: "
                                  "`achieved`/`frac` price the ALGORITHMIC work of the reference's scan — 18 FLOP/ray-sphere test + 60/ray — "
