@@ -389,7 +389,7 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 // the f32 test would accept with t below the current closest.  That test can accept a ray whose line misses
 // the sphere in real arithmetic (rounding of the discriminant, sphere.zig:66-72): the accepted point
 // o + t d then lies within r' of the centre, r'^2 = r^2 + g (2 |o - c|^2 + r^2), g = kListGamma (the bound the
-// primary pass's lists use, with the same 9x reserve; DESIGN.md section 2.2).  A box [lo, hi] that contains its
+// primary pass's lists use, with the same 9x reserve; DESIGN.md section 2.1b).  A box [lo, hi] that contains its
 // spheres (centre +- radius, rounded outwards) is therefore tested after growing it by
 //   mu = kTreeKappa * m,   m = max_axis max(|lo - o|, |hi - o|)  >=  r  and  >= |o - c| / sqrt 3  for each of its spheres,
 // kTreeKappa = 8e-3 >= sqrt(g) (sqrt 6 + 1) = 6.9e-3 >= (r' - r) / m; the rest covers the slab arithmetic

@@ -1,4 +1,4 @@
-"""The sphere tree of large scenes (scene_is_hit_tree, DESIGN.md section 2.2) against the scan over all spheres.
+"""The sphere tree of large scenes (scene_is_hit_tree, DESIGN.md section 2.1b) against the scan over all spheres.
 
 scene.zig:96-110 tests every sphere for every ray.  With PT_LIMIT_TREE_MIN_SPHERES = 0 the megakernel does exactly that
 (conservative LDS filter + exact pass); with a tree it walks boxes and gives the exact Sphere.is_hit only to the spheres
