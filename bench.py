@@ -85,6 +85,8 @@ def main():
                          "max(4, 16/N) by samples (a rank's launch is N times shorter, so its tail must be: measured at one rank's "
                          "eighth, tiles, chunk 8 / 16 = 22.9 / 23.7 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tree-min-spheres", type=int, default=None,
+                    help="A/B only: PT_LIMIT_TREE_MIN_SPHERES (library default 513; 0 = scan for every scene, 1 = sphere tree for every scene)")
     ap.add_argument("--spheres", type=int, default=0,
                     help="0 (default) = scene 21, the headline config; N > 0 = the synthetic random-sphere scene of N spheres "
                          "(BASELINE configs[4] uses 100000 with --spp 64 --split tiles)")
@@ -131,6 +133,9 @@ def main():
     scene = host.Scene().sceneSynthetic(args.spheres, 1) if args.spheres > 0 else host.Scene().setupScene(args.seed, 21)
     camera = host.Camera.preset(21, img.aspect_ratio)
     gpu = GpuContext(local_rank)
+    if args.tree_min_spheres is not None:
+        from path_tracer_amd import _lib
+        gpu.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, args.tree_min_spheres)
     gpu.set_scene(scene.spheres)
     gpu.set_camera(camera.pod)
     render_into = gpu_render_into(gpu)

@@ -159,7 +159,7 @@ struct KParams {
     const TreeNode *tnodes;
     const float4 *tgeom;
     const uint32_t *tprim;
-    uint32_t troot;
+    uint32_t troot, tnode_count;
 };
 
 // Pixel index of local slot `po`: the range itself, or the owner's interleaved tiles
@@ -399,9 +399,10 @@ struct TreeNode { float4 a, b, c; uint4 ch; }; // boxes of the two children: a =
 #ifndef PT_TREE_LEAF
 #define PT_TREE_LEAF 4 // measured 1 / 2 / 4: 280.3 / 259.3 / 253.7 ms per frame of the 100 000-sphere scene, 36.8 / 37.0 / 38.6 ms per 256 samples of 3 000 spheres
 #endif
-constexpr uint32_t kTreeLeaf = PT_TREE_LEAF; // spheres per leaf (at most 4: two bits of the leaf ref)
+constexpr uint32_t kTreeLeaf = PT_TREE_LEAF; // spheres per leaf (at most 8: three bits of the leaf ref)
+static_assert(kTreeLeaf >= 1 && kTreeLeaf <= 8, "leaf count field");
 constexpr uint32_t kTreeStack = 24;        // stack entries per lane = deepest tree walked (set_scene falls back to the scan beyond it)
-constexpr uint32_t kTreeLeafBit = 0x80000000u, kTreeNone = 0xffffffffu; // leaf ref: bit 31 | (count - 1) << 29 | first slot of the leaf arrays
+constexpr uint32_t kTreeLeafBit = 0x80000000u, kTreeNone = 0xffffffffu; // leaf ref: bit 31 | (count - 1) << 28 | first slot of the leaf arrays
 constexpr float kTreeKappa = 8e-3f;
 
 __device__ __forceinline__ bool tree_box(V3 o, V3 inv, float lox, float loy, float loz, float hix, float hiy, float hiz, float t_lo, float t_hi,
@@ -417,30 +418,112 @@ __device__ __forceinline__ bool tree_box(V3 o, V3 inv, float lox, float loy, flo
     return t_near <= t_far;
 }
 
-// s_stack: kTreeStack words per lane, word-major (entry e of thread tid at [e * kBlock + tid]).
-__device__ __forceinline__ void scene_is_hit_tree(const TreeNode *__restrict__ nodes, const float4 *__restrict__ tgeom, const uint32_t *__restrict__ tprim,
-                                                  uint32_t root, uint32_t *s_stack, uint32_t tid, bool active, V3 o, V3 d, float a, float t_min, float t_max,
+// Where a walk reads the tree from.  In global memory (large scenes): 32-bit refs, a stack of kTreeStack words per lane in
+// LDS, word-major (entry e of thread tid at [e * kBlock + tid]).
+struct TreeInGlobal {
+    const TreeNode *nodes; const float4 *tgeom; const uint32_t *tprim; uint32_t *stack;
+    static constexpr uint32_t kLeafBit = kTreeLeafBit, kNone = kTreeNone;
+    __device__ __forceinline__ static uint32_t first(uint32_t r) { return r & 0x0fffffffu; }
+    __device__ __forceinline__ static uint32_t count(uint32_t r) { return ((r >> 28) & 7u) + 1u; }
+    __device__ __forceinline__ void node(uint32_t i, float4 &A, float4 &B, float4 &C, uint32_t &c0, uint32_t &c1) const {
+        const TreeNode *nd = nodes + i;
+        A = nd->a; B = nd->b; C = nd->c;
+        const uint4 ch = nd->ch;
+        c0 = ch.x; c1 = ch.y;
+    }
+    __device__ __forceinline__ void sphere(uint32_t slot, float4 &g, uint32_t &id) const { g = tgeom[slot]; id = tprim[slot]; }
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t tid, uint32_t v) const { stack[sp * kBlock + tid] = v; }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp, uint32_t tid) const { return stack[sp * kBlock + tid]; }
+};
+// In LDS (scenes of one tile whose tree has at most kTreeLdsNodes inner nodes and kTreeLdsStack + 1 levels): the whole tree
+// is staged once per workgroup — a walk step is then an LDS round trip instead of a trip to L1/L2 (the walk from global
+// memory waited on memory 64 % of its wave cycles on scene 21).  16-bit refs: bit 15 leaf | (count - 1) << 9 | first slot (< 512).
+constexpr uint32_t kTreeLdsNodes = 256, kTreeLdsStack = 16;
+struct TreeInLds {
+    const float4 *boxes; const uint32_t *child; const float4 *tgeom; const uint16_t *tprim; uint16_t *stack;
+    static constexpr uint32_t kLeafBit = 0x8000u, kNone = 0xffffu;
+    __device__ __forceinline__ static uint32_t first(uint32_t r) { return r & 0x1ffu; }
+    __device__ __forceinline__ static uint32_t count(uint32_t r) { return ((r >> 9) & 7u) + 1u; }
+    __device__ __forceinline__ static uint32_t ref16(uint32_t r32) { // a ref of the global encoding
+        return (r32 & kTreeLeafBit) ? (0x8000u | (((r32 >> 28) & 7u) << 9) | (r32 & 0x1ffu)) : r32;
+    }
+    __device__ __forceinline__ void node(uint32_t i, float4 &A, float4 &B, float4 &C, uint32_t &c0, uint32_t &c1) const {
+        A = boxes[3u * i]; B = boxes[3u * i + 1u]; C = boxes[3u * i + 2u];
+        const uint32_t ch = child[i];
+        c0 = ch & 0xffffu; c1 = ch >> 16;
+    }
+    __device__ __forceinline__ void sphere(uint32_t slot, float4 &g, uint32_t &id) const { g = tgeom[slot]; id = tprim[slot]; }
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t tid, uint32_t v) const { stack[sp * kBlock + tid] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp, uint32_t tid) const { return stack[sp * kBlock + tid]; }
+};
+
+template <class Tree>
+__device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t root, uint32_t tid, bool active, V3 o, V3 d, float a, float t_min, float t_max,
                                                   float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters) {
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     // (a lane without a ray stays out: its parked NaN direction would pass every box — min/max drop NaN operands)
-    uint32_t cur = active ? root : kTreeNone, sp = 0;
+    uint32_t cur = active ? root : Tree::kNone, sp = 0;
     // One loop, both bodies: a lane holding a leaf tests its spheres in the same iteration in which others test boxes.
     // (Measured against "while-while" — inner nodes until every lane holds a leaf, then the leaves together: 63 vs 75 ms on
     // the 100 000-sphere scene, 43.5 vs 43.1 on 3 000 spheres, 30.2 vs 29.0 on scene 21 forced through the tree.)
+#ifdef PT_TREE_WW // A/B build: "while-while"
     for (;;) {
-        if (cur == kTreeNone && sp > 0u) cur = s_stack[--sp * kBlock + tid];
-        if (__ballot(cur != kTreeNone) == 0ull) break;
+        for (;;) {
+            const bool inner = (cur & Tree::kLeafBit) == 0u; // (kNone has the leaf bit)
+            if (__ballot(inner) == 0ull) break;
+            n_iters++;
+            if (inner) {
+                float4 A, B, C; uint32_t c0, c1;
+                T.node(cur, A, B, C, c0, c1);
+                float n0, n1;
+                const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
+                const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
+                if (h0 && h1) {
+                    const bool first0 = n0 <= n1;
+                    T.push(sp++, tid, first0 ? c1 : c0);
+                    cur = first0 ? c0 : c1;
+                } else if (h0 || h1) {
+                    cur = h0 ? c0 : c1;
+                } else {
+                    cur = sp > 0u ? T.pop(--sp, tid) : Tree::kNone;
+                }
+            }
+        }
+        if (__ballot(cur != Tree::kNone) == 0ull) break;
         n_iters++;
-        if (cur == kTreeNone) {
-            // nothing pending for this lane: it waits for the wave
-        } else if (cur & kTreeLeafBit) {
-            const uint32_t first = cur & 0x1fffffffu, cnt = ((cur >> 29) & 3u) + 1u;
+        if (cur != Tree::kNone) {
+            const uint32_t first = Tree::first(cur), cnt = Tree::count(cur);
 #pragma unroll
             for (uint32_t k = 0; k < kTreeLeaf; ++k) {
                 if (k < cnt) {
-                    const float4 g = tgeom[first + k];
-                    const uint32_t id = tprim[first + k];
+                    float4 g; uint32_t id;
+                    T.sphere(first + k, g, id);
+                    n_cands++;
+                    float t;
+                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
+                        if (t < closest || (t == closest && (int)id < hit)) { closest = t; hit = (int)id; }
+                    }
+                }
+            }
+            cur = sp > 0u ? T.pop(--sp, tid) : Tree::kNone;
+        }
+    }
+    return;
+#endif
+    for (;;) {
+        if (cur == Tree::kNone && sp > 0u) cur = T.pop(--sp, tid);
+        if (__ballot(cur != Tree::kNone) == 0ull) break;
+        n_iters++;
+        if (cur == Tree::kNone) {
+            // nothing pending for this lane: it waits for the wave
+        } else if (cur & Tree::kLeafBit) {
+            const uint32_t first = Tree::first(cur), cnt = Tree::count(cur);
+#pragma unroll
+            for (uint32_t k = 0; k < kTreeLeaf; ++k) {
+                if (k < cnt) {
+                    float4 g; uint32_t id;
+                    T.sphere(first + k, g, id);
                     n_cands++;
                     float t;
                     if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
@@ -449,23 +532,35 @@ __device__ __forceinline__ void scene_is_hit_tree(const TreeNode *__restrict__ n
                     }
                 }
             }
-            cur = kTreeNone;
+            cur = Tree::kNone;
         } else {
-            const TreeNode *nd = nodes + cur;
-            const float4 A = nd->a, B = nd->b, C = nd->c;
-            const uint4 ch = nd->ch;
+            float4 A, B, C; uint32_t c0, c1;
+            T.node(cur, A, B, C, c0, c1);
             float n0, n1;
             const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
             const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
             if (h0 && h1) {
                 const bool first0 = n0 <= n1; // nearer box first: a hit found there shortens (t_min, closest) for the boxes below the other
-                s_stack[sp++ * kBlock + tid] = first0 ? ch.y : ch.x;
-                cur = first0 ? ch.x : ch.y;
+                T.push(sp++, tid, first0 ? c1 : c0);
+                cur = first0 ? c0 : c1;
             } else {
-                cur = h0 ? ch.x : (h1 ? ch.y : kTreeNone);
+                cur = h0 ? c0 : (h1 ? c1 : Tree::kNone);
             }
         }
     }
+}
+
+// The tree of a one-tile scene into LDS (every thread of the workgroup; followed by a barrier).
+__device__ __forceinline__ void tree_stage_lds(const TreeNode *__restrict__ nodes, uint32_t n_nodes, const float4 *__restrict__ tgeom,
+                                               const uint32_t *__restrict__ tprim, uint32_t nspheres, float4 *s_boxes, uint32_t *s_child, float4 *s_tgeom,
+                                               uint16_t *s_tprim, uint32_t tid) {
+    for (uint32_t i = tid; i < n_nodes; i += kBlock) {
+        const TreeNode nd = nodes[i];
+        s_boxes[3u * i] = nd.a; s_boxes[3u * i + 1u] = nd.b; s_boxes[3u * i + 2u] = nd.c;
+        s_child[i] = TreeInLds::ref16(nd.ch.x) | (TreeInLds::ref16(nd.ch.y) << 16);
+    }
+    for (uint32_t i = tid; i < nspheres; i += kBlock) { s_tgeom[i] = tgeom[i]; s_tprim[i] = (uint16_t)tprim[i]; }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -478,27 +573,35 @@ __device__ __forceinline__ void scene_is_hit_tree(const TreeNode *__restrict__ n
 // through the scalar cache instead (s_load_dwordx16 into SGPR operands: no VGPRs, no LDS reads)
 // was measured 15 % slower on MI355X — 16 B per wave per test saturates the scalar cache, which
 // several CUs share, long before LDS.
-// TREE (with MULTI_TILE, i.e. tables in global memory): Scene.is_hit walks the sphere tree instead of scanning; no filter
-// table in LDS, no barriers — s_mask is the lanes' traversal stacks.
+// TREE: Scene.is_hit walks the sphere tree instead of scanning; no filter table, no barriers in the ray loop; the sphere
+// tables are read from global memory.  With MULTI_TILE the tree stays in global memory and s_mask is the lanes' stacks;
+// without (one-tile scenes) the whole tree is staged in LDS.
 template <bool DET, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
 __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
-    static_assert(!TREE || MULTI_TILE, "the tree variant reads the sphere tables from global memory");
+    constexpr bool TREE_LDS = TREE && !MULTI_TILE;
+    constexpr bool TABLES_LDS = !MULTI_TILE && !TREE;      // filter table, radii and materials of a one-tile scene
     __shared__ float4 s_filt[TREE ? 1 : kTile + kSub];      // (cx, cz, T, cy) filter records of the current tile
-    __shared__ uint32_t s_mask[TREE ? kTreeStack * kBlock : mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
+    __shared__ uint32_t s_mask[TREE ? (TREE_LDS ? 1 : kTreeStack * kBlock) : mask_tile(MULTI_TILE) / 32 * kBlock]; // candidate bit words, word-major (conflict-free)
     __shared__ float s_ycy[kTile / 32];                     // per mask word of the tile: shared centre ordinate, or NaN
+    __shared__ float4 s_tboxes[TREE_LDS ? 3 * kTreeLdsNodes : 1];
+    __shared__ uint32_t s_tchild[TREE_LDS ? kTreeLdsNodes : 1];
+    __shared__ float4 s_tgeom[TREE_LDS ? kTile : 1];
+    __shared__ uint16_t s_tprim[TREE_LDS ? kTile : 2];
+    __shared__ uint16_t s_tstack[TREE_LDS ? kTreeLdsStack * kBlock : 2];
     // single-tile scenes keep the exact-test radius and the materials in LDS too (no global
     // latency in the exact pass / shading); larger scenes read them from HBM/L2
-    __shared__ float s_radius[MULTI_TILE ? 1 : kTile];
-    __shared__ float s_inv_radius[MULTI_TILE ? 1 : kTile];
-    __shared__ float4 s_mat[MULTI_TILE ? 1 : kTile];   // (albedo r, g, b, param) | (1/ri, r0, 0, ri); kind in s_kind
-    __shared__ uint8_t s_kind[MULTI_TILE ? 4 : kTile];
+    __shared__ float s_radius[TABLES_LDS ? kTile : 1];
+    __shared__ float s_inv_radius[TABLES_LDS ? kTile : 1];
+    __shared__ float4 s_mat[TABLES_LDS ? kTile : 1];   // (albedo r, g, b, param) | (1/ri, r0, 0, ri); kind in s_kind
+    __shared__ uint8_t s_kind[TABLES_LDS ? kTile : 4];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * kBlock + tid;
 
     const uint32_t n_pad = (P.nspheres + kPad - 1) / kPad * kPad;
-    if (!MULTI_TILE) {
+    if (TREE_LDS) tree_stage_lds(P.tnodes, P.tnode_count, P.tgeom, P.tprim, P.nspheres, s_tboxes, s_tchild, s_tgeom, s_tprim, tid);
+    if (TABLES_LDS) {
         for (uint32_t i = tid; i < n_pad; i += kBlock) s_filt[i] = P.filt[i];
         if (tid < (uint32_t)(kTile / 32)) s_ycy[tid] = P.ycy[tid];
         for (uint32_t i = tid; i < P.nspheres; i += kBlock) {
@@ -511,13 +614,13 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     }
     // exact sphere / material lookups (LDS for single-tile scenes)
     auto geom_of = [&](uint32_t j) -> float4 {
-        if (MULTI_TILE) return P.geom[j];
+        if (!TABLES_LDS) return P.geom[j];
         const float4 f = s_filt[j]; // (cx, cz, T, cy)
         return make_float4(f.x, f.w, f.y, s_radius[j]);
     };
-    auto inv_radius_of = [&](uint32_t j) -> float { return MULTI_TILE ? P.inv_radius[j] : s_inv_radius[j]; };
-    auto mat_of = [&](uint32_t j) -> float4 { return MULTI_TILE ? P.mat[j] : s_mat[j]; };
-    auto kind_of = [&](uint32_t j) -> uint32_t { return MULTI_TILE ? P.kind[j] : (uint32_t)s_kind[j]; };
+    auto inv_radius_of = [&](uint32_t j) -> float { return TABLES_LDS ? s_inv_radius[j] : P.inv_radius[j]; };
+    auto mat_of = [&](uint32_t j) -> float4 { return TABLES_LDS ? s_mat[j] : P.mat[j]; };
+    auto kind_of = [&](uint32_t j) -> uint32_t { return TABLES_LDS ? (uint32_t)s_kind[j] : P.kind[j]; };
 
     // per-lane path state
     bool alive = true;      // lane still has (or can get) work
@@ -687,8 +790,12 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        if (TREE)
-            scene_is_hit_tree(P.tnodes, P.tgeom, P.tprim, P.troot, s_mask, tid, alive && !need_path, o, d, a, P.t_min, P.t_max, closest, hit, n_cands, n_flush_iters);
+        if (TREE_LDS)
+            scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, TreeInLds::ref16(P.troot), tid, alive && !need_path, o, d, a, P.t_min, P.t_max,
+                              closest, hit, n_cands, n_flush_iters);
+        else if (TREE)
+            scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, P.troot, tid, alive && !need_path, o, d, a, P.t_min, P.t_max, closest, hit, n_cands,
+                              n_flush_iters);
         else
             scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                               n_cands, n_flush_iters, t_flush);
@@ -867,7 +974,7 @@ __device__ __forceinline__ void list_tree_walk(const TreeNode *__restrict__ node
     uint32_t cur = active ? root : kTreeNone, sp = 0;
     while (cur != kTreeNone) {
         if (cur & kTreeLeafBit) {
-            const uint32_t first = cur & 0x1fffffffu, cnt = ((cur >> 29) & 3u) + 1u;
+            const uint32_t first = TreeInGlobal::first(cur), cnt = TreeInGlobal::count(cur);
             bool go_on = true;
             for (uint32_t k = 0; k < cnt; ++k) go_on = leaf(first + k) && go_on;
             cur = (go_on && sp > 0u) ? s_stack[--sp * 256u + tid] : kTreeNone;
@@ -1551,10 +1658,17 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
 }
 
 // PT_FN_SCENE_HIT_TREE: the same through the sphere tree (same record).
-__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *in, float *out, uint32_t n, const TreeNode *nodes, const float4 *tgeom,
-                                                                  const uint32_t *tprim, uint32_t root, const float4 *g_geom, float t_min, float t_max) {
-    __shared__ uint32_t s_stack[kTreeStack * kBlock];
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *in, float *out, uint32_t n, const TreeNode *nodes, uint32_t n_nodes, const float4 *tgeom,
+                                                                  const uint32_t *tprim, uint32_t nspheres, uint32_t root, const float4 *g_geom, float t_min, float t_max) {
+    __shared__ uint32_t s_stack[LDS ? 1 : kTreeStack * kBlock];
+    __shared__ float4 s_tboxes[LDS ? 3 * kTreeLdsNodes : 1];
+    __shared__ uint32_t s_tchild[LDS ? kTreeLdsNodes : 1];
+    __shared__ float4 s_tgeom[LDS ? kTile : 1];
+    __shared__ uint16_t s_tprim[LDS ? kTile : 2];
+    __shared__ uint16_t s_tstack[LDS ? kTreeLdsStack * kBlock : 2];
     const uint32_t tid = threadIdx.x;
+    if (LDS) tree_stage_lds(nodes, n_nodes, tgeom, tprim, nspheres, s_tboxes, s_tchild, s_tgeom, s_tprim, tid);
     const uint32_t i = blockIdx.x * kBlock + tid;
     const bool live = i < n;
     const float *r = in + (size_t)(live ? i : 0) * 6;
@@ -1563,7 +1677,8 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     float closest = t_max;
     int hit = -1;
     uint32_t n_cands = 0, n_iters = 0;
-    scene_is_hit_tree(nodes, tgeom, tprim, root, s_stack, tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    if (LDS) scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, TreeInLds::ref16(root), tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    else scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, root, tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
     if (!live) return;
     float *w = out + (size_t)i * 8;
     V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
@@ -1601,7 +1716,7 @@ struct ptgpu_ctx {
     TreeNode *d_tnodes = nullptr; float4 *d_tgeom = nullptr; uint32_t *d_tprim = nullptr;
     uint32_t tree_root = 0, tree_nodes = 0, tree_depth = 0;
     uint32_t tree_min_spheres = (uint32_t)kTile + 1u; // PT_LIMIT_TREE_MIN_SPHERES
-    int resident_tree[2] = {0, 0};                   // [det]: workgroups per CU of the tree variants
+    int resident_tree[2][2] = {{0, 0}, {0, 0}};      // [det][multi]: workgroups per CU of the tree variants (multi = 0: tree staged in LDS)
     bool have_camera = false;
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
@@ -1692,9 +1807,11 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1] = r;
-        for (int i = 0; i < 2; ++i) if (ctx->resident_tree[i] <= 0) ctx->resident_tree[i] = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][0] = r;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident_tree[i][j] <= 0) ctx->resident_tree[i][j] = 1;
     }
     if (e != hipSuccess || !ctx->d_scratch) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -1810,6 +1927,7 @@ struct TreeBuild {
     std::vector<float4> tgeom;
     std::vector<uint32_t> tprim;
     uint32_t root = 0, depth = 0;
+    bool sah = true; // false: median splits only (at most n / 2 leaves, ceil(log2(n / kTreeLeaf)) + 1 levels)
 };
 struct TreeBox {
     float lo[3], hi[3];
@@ -1842,7 +1960,7 @@ static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx
             T.tgeom.push_back(make_float4(s.cx, s.cy, s.cz, s.radius));
             T.tprim.push_back(idx[i]);
         }
-        return kTreeLeafBit | ((e - b - 1u) << 29) | first;
+        return kTreeLeafBit | ((e - b - 1u) << 28) | first;
     }
     auto centre = [&](uint32_t i, int k) -> float { const pt_sphere &s = sp[i]; return k == 0 ? s.cx : k == 1 ? s.cy : s.cz; };
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -1875,7 +1993,7 @@ static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx
     }
     uint32_t mid = b + (e - b) / 2u;
     const uint32_t larger = std::max(best_left, (e - b) - best_left);
-    if (best_axis >= 0 && level + 1u + tree_levels_of_median_split(larger) <= kTreeStack) {
+    if (T.sah && best_axis >= 0 && level + 1u + tree_levels_of_median_split(larger) <= kTreeStack) {
         mid = (uint32_t)(std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t i) { return bin_of(i, best_axis) <= best_bin; }) - idx.begin());
     } else {
         int axis = 0;
@@ -1899,7 +2017,7 @@ static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx
     return me;
 }
 static bool tree_build(const pt_sphere *sp, uint32_t n, TreeBuild &T) {
-    if (n > 0x1fffffffu) return false;
+    if (n > 0x0fffffffu) return false;
     for (uint32_t i = 0; i < n; ++i)
         if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].radius)) return false;
     std::vector<uint32_t> idx(n);
@@ -1946,7 +2064,14 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     // Build the new tables aside and swap them in only when every step succeeded: a failure leaves the
     // context with its previous scene intact (never half-updated).
     TreeBuild tree;
-    const bool with_tree = ctx->tree_min_spheres != 0u && n >= ctx->tree_min_spheres && tree_build(spheres, n, tree);
+    bool with_tree = ctx->tree_min_spheres != 0u && n >= ctx->tree_min_spheres && tree_build(spheres, n, tree);
+    // a one-tile scene walks its tree in LDS: it has to fit there.  Median splits alone always do (leaves of two or more
+    // spheres: at most 255 inner nodes and 9 levels for 512 spheres).
+    if (with_tree && n_pad <= (uint32_t)kTile && (tree.nodes.size() > kTreeLdsNodes || tree.depth > kTreeLdsStack + 1u)) {
+        tree = TreeBuild();
+        tree.sah = false;
+        with_tree = tree_build(spheres, n, tree) && tree.nodes.size() <= kTreeLdsNodes && tree.depth <= kTreeLdsStack + 1u;
+    }
     constexpr int kTables = 9;
     void *fresh[kTables] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const void *src[kTables] = {filt.data(), geom.data(), mat.data(), kind.data(), inv_radius.data(), ycy.data(), tree.nodes.data(), tree.tgeom.data(),
@@ -2057,8 +2182,13 @@ struct Workspace {
 template <bool PRIMARY>
 static void launch_megakernel_p(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
     if (P.tnodes) {
-        if (det) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        if (det) {
+            if (multi) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+            else hipLaunchKernelGGL((pt_megakernel<true, false, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        } else {
+            if (multi) hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+            else hipLaunchKernelGGL((pt_megakernel<false, false, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        }
         return;
     }
     if (det) {
@@ -2098,10 +2228,10 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     const uint32_t nchunks = (s1 - s0 + chunk - 1) / chunk;
 
     const bool tree = ctx->tree_nodes != 0u;
-    const bool multi = tree || ctx->n_pad > (uint32_t)kTile; // (the tree variants read the sphere tables from global memory, like multi-tile scenes)
+    const bool multi = ctx->n_pad > (uint32_t)kTile; // with a tree: walked in global memory (else staged in LDS)
     const bool det = cfg->mode == 1;
     // persistent grid: as many workgroups per CU as the kernel variant can keep resident
-    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : tree ? ctx->resident_tree[det ? 1 : 0] : ctx->resident[det ? 1 : 0][multi ? 1 : 0];
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (tree ? ctx->resident_tree : ctx->resident)[det ? 1 : 0][multi ? 1 : 0];
     const uint32_t grid = (uint32_t)(ctx->compute_units * bpc);
     const uint32_t total_threads = grid * kBlock;
     const size_t stack_need = (size_t)(cfg->rebounds ? cfg->rebounds : 1u) * total_threads * sizeof(uint32_t);
@@ -2186,7 +2316,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
-    P.tnodes = tree ? ctx->d_tnodes : nullptr; P.tgeom = ctx->d_tgeom; P.tprim = ctx->d_tprim; P.troot = ctx->tree_root;
+    P.tnodes = tree ? ctx->d_tnodes : nullptr; P.tgeom = ctx->d_tgeom; P.tprim = ctx->d_tprim; P.troot = ctx->tree_root; P.tnode_count = ctx->tree_nodes;
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
@@ -2220,7 +2350,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
                 HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg], stream));
             }
             const uint32_t second = (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u;
-            if (tree)
+            if (tree && multi) // (a one-tile scene's lists come from the loop over its spheres either way: 1.5 ms per launch, ascending order)
                 hipLaunchKernelGGL(pt_primary_lists<true>, dim3((P.npix + 255u) / 256u), dim3(256), 0, stream, LC, cfg->width, cfg->height, slot0, P.npix,
                                    cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, (const ListSphere *)ctx->d_lsph,
                                    ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min, second, d_lists,
@@ -2424,9 +2554,14 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
         if (fn == PT_FN_FILTER_BIT) {
             hipLaunchKernelGGL(pt_debug_filter_bit, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, (const float *)d_in, (const float *)d_thr, d_out, n);
         } else if (fn == PT_FN_SCENE_HIT_TREE) {
-            hipLaunchKernelGGL(pt_debug_scene_hit_tree, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
-                               (const TreeNode *)ctx->d_tnodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->tree_root,
-                               (const float4 *)ctx->d_geom, t_min, t_max);
+            if (ctx->n_pad <= (uint32_t)kTile) // the walk the megakernel would use for this scene: tree staged in LDS
+                hipLaunchKernelGGL(pt_debug_scene_hit_tree<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                                   (const TreeNode *)ctx->d_tnodes, ctx->tree_nodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->nspheres,
+                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max);
+            else
+                hipLaunchKernelGGL(pt_debug_scene_hit_tree<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                                   (const TreeNode *)ctx->d_tnodes, ctx->tree_nodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->nspheres,
+                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max);
         } else if (fn == PT_FN_SCENE_HIT_FILTERED) {
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)
