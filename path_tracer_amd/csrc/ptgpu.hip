@@ -160,6 +160,7 @@ struct KParams {
     const float4 *tgeom;
     const uint32_t *tprim;
     uint32_t troot, tnode_count;
+    uint32_t tree_exit_at; // a ray step's walk ends once at most this many lanes are still walking (0: when none is)
 };
 
 // Pixel index of local slot `po`: the range itself, or the owner's interleaved tiles
@@ -457,63 +458,25 @@ struct TreeInLds {
     __device__ __forceinline__ uint32_t pop(uint32_t sp, uint32_t tid) const { return stack[sp * kBlock + tid]; }
 };
 
+// A walk can be left unfinished and resumed: `cur` and `sp` are the lane's position (cur == kNone && sp == 0: finished; the
+// stack lives in LDS), closest / hit its result so far.  exit_at > 0: the wave leaves the loop as soon as at most that many
+// lanes are still walking, provided some lane has finished (the megakernel then shades the finished lanes and gives
+// them their next rays while the stragglers keep their place; they go on in the next ray step).  exit_at = 0: to the end.
 template <class Tree>
-__device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t root, uint32_t tid, bool active, V3 o, V3 d, float a, float t_min, float t_max,
+__device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t exit_at, uint32_t tid, V3 o, V3 d, float a, float t_min, float t_max,
                                                   float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters) {
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    // (a lane without a ray stays out: its parked NaN direction would pass every box — min/max drop NaN operands)
-    uint32_t cur = active ? root : Tree::kNone, sp = 0;
+    // (a lane without a ray stays out — the caller gives it cur = kNone: its parked NaN direction would pass every box, min/max drop NaN operands)
+    const unsigned long long walking0 = __ballot(cur != Tree::kNone || sp > 0u);
     // One loop, both bodies: a lane holding a leaf tests its spheres in the same iteration in which others test boxes.
     // (Measured against "while-while" — inner nodes until every lane holds a leaf, then the leaves together: 63 vs 75 ms on
     // the 100 000-sphere scene, 43.5 vs 43.1 on 3 000 spheres, 30.2 vs 29.0 on scene 21 forced through the tree.)
-#ifdef PT_TREE_WW // A/B build: "while-while"
-    for (;;) {
-        for (;;) {
-            const bool inner = (cur & Tree::kLeafBit) == 0u; // (kNone has the leaf bit)
-            if (__ballot(inner) == 0ull) break;
-            n_iters++;
-            if (inner) {
-                float4 A, B, C; uint32_t c0, c1;
-                T.node(cur, A, B, C, c0, c1);
-                float n0, n1;
-                const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
-                const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
-                if (h0 && h1) {
-                    const bool first0 = n0 <= n1;
-                    T.push(sp++, tid, first0 ? c1 : c0);
-                    cur = first0 ? c0 : c1;
-                } else if (h0 || h1) {
-                    cur = h0 ? c0 : c1;
-                } else {
-                    cur = sp > 0u ? T.pop(--sp, tid) : Tree::kNone;
-                }
-            }
-        }
-        if (__ballot(cur != Tree::kNone) == 0ull) break;
-        n_iters++;
-        if (cur != Tree::kNone) {
-            const uint32_t first = Tree::first(cur), cnt = Tree::count(cur);
-#pragma unroll
-            for (uint32_t k = 0; k < kTreeLeaf; ++k) {
-                if (k < cnt) {
-                    float4 g; uint32_t id;
-                    T.sphere(first + k, g, id);
-                    n_cands++;
-                    float t;
-                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
-                        if (t < closest || (t == closest && (int)id < hit)) { closest = t; hit = (int)id; }
-                    }
-                }
-            }
-            cur = sp > 0u ? T.pop(--sp, tid) : Tree::kNone;
-        }
-    }
-    return;
-#endif
     for (;;) {
         if (cur == Tree::kNone && sp > 0u) cur = T.pop(--sp, tid);
-        if (__ballot(cur != Tree::kNone) == 0ull) break;
+        const unsigned long long walking = __ballot(cur != Tree::kNone);
+        if (walking == 0ull) break;
+        if (exit_at != 0u && walking != walking0 && (uint32_t)__popcll(walking) <= exit_at) break;
         n_iters++;
         if (cur == Tree::kNone) {
             // nothing pending for this lane: it waits for the wave
@@ -632,6 +595,10 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     V3 accum = v3(0.f, 0.f, 0.f);
     V3 o = v3(0.f, 0.f, 0.f), d = v3(kNaN, kNaN, kNaN); // parked (see phase A) until the first path starts
     uint32_t bounce = 0;
+    // tree variants: the lane's walk (it may span ray steps, see scene_is_hit_tree) and its result so far
+    uint32_t t_cur = TREE_LDS ? TreeInLds::kNone : TreeInGlobal::kNone, t_sp = 0;
+    float t_closest = 0.f;
+    int t_hit = -1;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
     uint32_t n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0; // per-lane counts (widened when the wave sums them)
@@ -790,16 +757,25 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
         const float a = vlen2(d); // sphere.zig:68
         float closest = P.t_max;
         int hit = -1;
-        if (TREE_LDS)
-            scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, TreeInLds::ref16(P.troot), tid, alive && !need_path, o, d, a, P.t_min, P.t_max,
-                              closest, hit, n_cands, n_flush_iters);
-        else if (TREE)
-            scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, P.troot, tid, alive && !need_path, o, d, a, P.t_min, P.t_max, closest, hit, n_cands,
-                              n_flush_iters);
-        else
+        bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
+        if (TREE) {
+            constexpr uint32_t kNone = TREE_LDS ? TreeInLds::kNone : TreeInGlobal::kNone;
+            const bool walking = t_cur != kNone || t_sp != 0u;
+            if (tracing && !walking) { // a new ray: start its walk
+                t_cur = TREE_LDS ? TreeInLds::ref16(P.troot) : P.troot;
+                t_closest = P.t_max; t_hit = -1;
+            }
+            if (TREE_LDS)
+                scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
+                                  t_hit, n_cands, n_flush_iters);
+            else
+                scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest, t_hit,
+                                  n_cands, n_flush_iters);
+            tracing = tracing && t_cur == kNone && t_sp == 0u; // lanes still walking skip this step's shading and keep their ray
+            closest = t_closest; hit = t_hit;
+        } else
             scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                               n_cands, n_flush_iters, t_flush);
-        const bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
         if (tracing) n_rays++;
         n_wave_steps++;
         PT_STAMP(tC0);
@@ -1677,8 +1653,14 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     float closest = t_max;
     int hit = -1;
     uint32_t n_cands = 0, n_iters = 0;
-    if (LDS) scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, TreeInLds::ref16(root), tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
-    else scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, root, tid, live, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    uint32_t sp = 0;
+    if (LDS) {
+        uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone;
+        scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    } else {
+        uint32_t cur = live ? root : kTreeNone;
+        scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+    }
     if (!live) return;
     float *w = out + (size_t)i * 8;
     V3 p = v3(0, 0, 0), nn = v3(0, 0, 0);
@@ -2317,6 +2299,11 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.part = (nchunks == 1) ? d_rgb_sum : ws.part; // one chunk: sums go straight to the frame
     P.stack = ws.stack; P.counters = ws.counters;
     P.tnodes = tree ? ctx->d_tnodes : nullptr; P.tgeom = ctx->d_tgeom; P.tprim = ctx->d_tprim; P.troot = ctx->tree_root; P.tnode_count = ctx->tree_nodes;
+    // When a ray step's walk is left to shade the finished lanes (scene_is_hit_tree): the longer the walks, the earlier it pays.
+    // Measured per 256 samples of 1080p, threshold 0 / 4 / 8 / 12 / 16 / 24 / 32 lanes: scene 21 in LDS 40.7 / 39.8 / 39.7 / - / 40.7 / 41.8 / 44.1 ms,
+    // 3 000 spheres 41.1 / - / 37.2 / 37.2 / 37.6 / 38.5 / 40.3, 100 000 spheres 276.5 / - / 261.0 / 253.6 / 245.5 / 226.4 / 224.6.
+    P.tree_exit_at = !multi ? 8u : (ctx->tree_nodes > 8192u ? 24u : 12u);
+    { const char *e = getenv("PTGPU_TREE_EXIT_AT"); if (e) P.tree_exit_at = (uint32_t)atoi(e); } // A/B runs
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
