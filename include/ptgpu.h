@@ -278,12 +278,13 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * shows sends on (scattered, mirrored or refracted from near the pixel's central hit point) against a second per-pixel list;
  * 1 stops it after the camera ray.  Results do not depend on it.
  *
- * PT_LIMIT_TREE_MIN_SPHERES (default 513 = one LDS tile of the scan + 1; 0 = never): scenes of at least this many
- * spheres are traced through a tree of boxes over the spheres instead of the scan over all of them (scene.zig:96-110
- * tests every sphere for every ray; the tree only skips spheres the reference's f32 test provably rejects, and the
- * closest hit is chosen by (t, index) as the ascending scan chooses it: same hits, bit for bit).  The tree is built
- * by ptgpu_set_scene (host, O(n log n)): set the limit before uploading the scene.  Scenes with a non-finite centre
- * or radius, or deeper than the traversal stack (possible beyond 3.3e7 spheres), keep the scan. */
+ * PT_LIMIT_TREE_MIN_SPHERES (default 256; 0 = never): scenes of at least this many spheres are traced through a tree
+ * of boxes over the spheres instead of the scan over all of them (scene.zig:96-110 tests every sphere for every ray;
+ * the tree only skips spheres the reference's f32 test provably rejects, and the closest hit is chosen by (t, index)
+ * as the ascending scan chooses it: same hits, bit for bit).  Scenes of up to 512 spheres walk the tree in LDS, larger
+ * ones in global memory.  The tree is built by ptgpu_set_scene (host, O(n log n)): set the limit before uploading
+ * the scene.  Scenes with a non-finite centre or radius, or deeper than the traversal stack (possible beyond 3.3e7
+ * spheres), keep the scan. */
 enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1, PT_LIMIT_PRIMARY_BOUNCES = 2, PT_LIMIT_TREE_MIN_SPHERES = 3 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
 

@@ -28,7 +28,7 @@ PT_LIMIT_PARTIAL_BYTES = 0
 PT_LIMIT_PRIMARY_BYTES = 1
 PT_LIMIT_PRIMARY_BOUNCES = 2
 PT_LIMIT_TREE_MIN_SPHERES = 3
-PT_TREE_MIN_SPHERES_DEFAULT = 513      # the library's default: one LDS tile of the scan + 1
+PT_TREE_MIN_SPHERES_DEFAULT = 256      # the library's default
 PT_PRIMARY_BYTES_DEFAULT = 96 << 30   # the library's default for PT_LIMIT_PRIMARY_BYTES
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 

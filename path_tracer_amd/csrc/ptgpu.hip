@@ -1697,7 +1697,7 @@ struct ptgpu_ctx {
     // sphere tree of the uploaded scene (tree_nodes = 0: none, the scan serves it)
     TreeNode *d_tnodes = nullptr; float4 *d_tgeom = nullptr; uint32_t *d_tprim = nullptr;
     uint32_t tree_root = 0, tree_nodes = 0, tree_depth = 0;
-    uint32_t tree_min_spheres = (uint32_t)kTile + 1u; // PT_LIMIT_TREE_MIN_SPHERES
+    uint32_t tree_min_spheres = 256u;                 // PT_LIMIT_TREE_MIN_SPHERES (measured: the walk in LDS overtakes the scan between 150 and 250 spheres)
     int resident_tree[2][2] = {{0, 0}, {0, 0}};      // [det][multi]: workgroups per CU of the tree variants (multi = 0: tree staged in LDS)
     bool have_camera = false;
     Cam cam;

@@ -55,12 +55,17 @@ def _compare_hits(gpu, rays, t_min, t_max):
     return scan
 
 
-def test_tree_is_built_for_large_scenes_only(gpu):
+def test_tree_is_built_for_scenes_of_256_spheres_and_more(gpu):
     from path_tracer_amd import _lib, host
-    gpu.set_scene(host.Scene().setupScene(456, 21).spheres)                 # 488 spheres: one LDS tile
+    gpu.set_scene(host.Scene().setupScene(456, 19).spheres)                 # 5 spheres
     assert gpu.tree_info() == {"nodes": 0, "depth": 0}
     with pytest.raises(Exception):
         gpu.debug_eval(_lib.PT_FN_SCENE_HIT_TREE, np.zeros((1, 6), np.float32))
+    gpu.set_scene(host.Scene().sceneSynthetic(255, 7).spheres)
+    assert gpu.tree_info()["nodes"] == 0
+    gpu.set_scene(host.Scene().setupScene(456, 21).spheres)                 # 488 spheres: one LDS tile, the tree is walked in LDS
+    info = gpu.tree_info()
+    assert 488 // 4 - 1 <= info["nodes"] <= 256 and 8 <= info["depth"] <= 17
     big = host.Scene().sceneSynthetic(3000, 7).spheres
     gpu.set_scene(big)
     info = gpu.tree_info()

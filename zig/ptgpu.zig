@@ -92,7 +92,7 @@ pub extern fn ptgpu_noalloc_scratch_bytes() u64;
 pub const PT_LIMIT_PARTIAL_BYTES: c_int = 0;
 pub const PT_LIMIT_PRIMARY_BYTES: c_int = 1;
 pub const PT_LIMIT_PRIMARY_BOUNCES: c_int = 2; // 1: camera rays only, 2 (default): also the rays scattered off each pixel's main diffuse sphere
-pub const PT_LIMIT_TREE_MIN_SPHERES: c_int = 3; // scenes of at least this many spheres (default 513; 0: never) are traced through a sphere tree; set before ptgpu_set_scene
+pub const PT_LIMIT_TREE_MIN_SPHERES: c_int = 3; // scenes of at least this many spheres (default 256; 0: never) are traced through a sphere tree; set before ptgpu_set_scene
 pub extern fn ptgpu_set_limit(ctx: *PtCtx, which: c_int, value: u64) c_int;
 pub extern fn ptgpu_tree_info(ctx: *const PtCtx, nodes: ?*u32, depth: ?*u32) c_int;
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
