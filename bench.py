@@ -229,15 +229,18 @@ def main():
                          "spheres": nsph, "shared_ordinate_tests": shared,
                          "basis": "algorithmic",
                          "executed_frac": None if tree["nodes"] else (scan_rays * ((nsph - shared) * 15.0 + shared * 11.0 + 60.0)) / (m_ms * 1e-3) / PEAK_FP32_VALU,
-                         "scene_is_hit": ("sphere tree: %d inner nodes, %d levels, %.1f exact sphere tests per ray" % (tree["nodes"], tree["depth"], cands / max(rays, 1)))
+                         "scene_is_hit": ("sphere tree (%s): %d inner nodes, %d levels, %.1f exact sphere tests per ray instead of %d; the algorithmic "
+                                          "fractions count the tests of the reference's scan, most of which the tree never makes"
+                                          % ("walked in LDS" if nsph <= 512 else "walked in global memory", tree["nodes"], tree["depth"], cands / max(rays, 1), nsph))
                                          if tree["nodes"] else "filter scan over all spheres + exact pass",
                          "render": render,
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d) of the dominant kernel, pt_megakernel: "
                                  "`achieved`/`frac` price the ALGORITHMIC work of the reference's scan — 18 FLOP/ray-sphere test + 60/ray — "
                                  "for the device-counted rays the megakernel traces, over its HIP-event time in rank 0's render (`launches` "
                                  "segment launches; rocprofv3's average duration x launches agrees): an algorithmic-work rate, not hardware "
-                                 "utilisation.  `executed_frac` prices what its filter scan executes per test (7 FMA + 1 compare = 15 FLOP; "
-                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words).  `render.primary_rays` rays — the camera rays and "
+                                 "utilisation.  `executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP; "
+                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words); null when `scene_is_hit` is the sphere tree "
+                                 "(scenes of 256 spheres and more: boxes select which spheres get the reference's exact test, same hits bit for bit).  `render.primary_rays` rays — the camera rays and "
                                  "(`of_which_second_bounce`) the rays scattered off each pixel's main diffuse sphere — never reach the "
                                  "megakernel: the primary pass resolves them against per-pixel candidate lists (same closest hit, bit for bit).  `render` prices the WHOLE render the same way — the reference's scan for "
                                  "every ray over the time of all tracing kernels — which is why its algorithmic_frac can pass 1.  "

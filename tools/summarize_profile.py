@@ -45,10 +45,15 @@ rl = bench["roofline"]
 if "wave_steps_per_launch" in rl:
     steps = rl["wave_steps_per_launch"] * rl.get("launches", 1)
     per_step = vals["SQ_INSTS_VALU"] / steps
-    scan = rl["shared_ordinate_tests"] * 7 + (rl["spheres"] - rl["shared_ordinate_tests"]) * 9
     derived["VALU wave-instructions per ray step (SQ_INSTS_VALU / wave steps of the launch)"] = per_step
-    derived["of which the filter scan (7 per test in shared-ordinate words, 9 otherwise)"] = scan
-    derived["VALU wave-instructions per ray step outside the scan"] = per_step - scan
+    if str(rl.get("scene_is_hit", "")).startswith("sphere tree"):
+        # (a ray step of the tree variants ends when few lanes are still walking: steps are shorter and more than rays / 64)
+        derived["ray steps per 64 rays of the launch"] = steps * 64.0 / max(rl["rays_per_launch"] * rl.get("launches", 1), 1.0)
+        derived["VALU wave-instructions per 64 rays"] = vals["SQ_INSTS_VALU"] / max(rl["rays_per_launch"] * rl.get("launches", 1) / 64.0, 1.0)
+    else:
+        scan = rl["shared_ordinate_tests"] * 7 + (rl["spheres"] - rl["shared_ordinate_tests"]) * 9
+        derived["of which the filter scan (7 per test in shared-ordinate words, 9 otherwise)"] = scan
+        derived["VALU wave-instructions per ray step outside the scan"] = per_step - scan
     derived["SALU wave-instructions per ray step"] = vals["SQ_INSTS_SALU"] / steps
     derived["LDS wave-instructions per ray step"] = vals["SQ_INSTS_LDS"] / steps
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
