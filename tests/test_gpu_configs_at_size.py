@@ -89,3 +89,39 @@ def test_config4_one_rank_tile_share_100k_spheres(orc, gpu):
         rc, ref, _ = orc.render_sum(scene.spheres, ocam, ocfg, nthreads=1)
         assert rc == 0
         np.testing.assert_array_equal(flat[idx], ref.reshape(-1, 3)[idx])
+
+
+def test_config4_whole_frame_tile_shares_and_a_band_through_the_scan(gpu):
+    """configs[4] at full size through the sphere tree: the eight owners' tile shares add up to the one-GPU frame exactly,
+    and a band of 16 rows traced through the scan over all 100 000 spheres (PT_LIMIT_TREE_MIN_SPHERES = 0) has the same bits."""
+    from path_tracer_amd import _lib, host
+    scene = host.Scene().sceneSynthetic(100000, 1)
+    gpu.set_scene(scene.spheres)
+    assert gpu.tree_info()["nodes"] > 0
+    gpu.set_camera(host.Camera.preset(21).pod)
+    img = host.Image(1920)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=64, rebounds=50)       # 256 paths per pixel
+    whole = gpu.render_sum(host.make_pt_config(img, rt, seed=1, chunk=16))
+    st = gpu.stats()
+    assert st.paths == img.num_pixels * 256 and st.not_unit == 0 and st.primary_rays > 0
+    acc = np.zeros_like(whole)
+    rays = 0
+    for owner in range(8):
+        acc += gpu.render_sum(host.make_pt_config(img, rt, seed=1, chunk=16, tile_pixels=256, tile_count=8, tile_index=owner))
+        rays += gpu.stats().rays
+    assert rays == st.rays
+    np.testing.assert_array_equal(acc, whole)       # other owners' pixels are 0: x + 0 = x
+    i0, i1 = 600 * img.width, 616 * img.width
+    band_cfg = host.make_pt_config(img, rt, seed=1, chunk=16, istart=i0, istop=i1)
+    band_tree = gpu.render_sum(band_cfg)
+    rays_tree = gpu.stats().rays
+    try:
+        gpu.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, 0)
+        gpu.set_scene(scene.spheres)
+        assert gpu.tree_info()["nodes"] == 0
+        band_scan = gpu.render_sum(band_cfg)
+        assert gpu.stats().rays == rays_tree
+    finally:
+        gpu.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, _lib.PT_TREE_MIN_SPHERES_DEFAULT)
+    np.testing.assert_array_equal(band_tree, band_scan)
+    np.testing.assert_array_equal(band_tree.reshape(-1, 3)[i0:i1], whole.reshape(-1, 3)[i0:i1])
