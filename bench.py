@@ -156,7 +156,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, list2_rays, segments, cands = [], [], 0, 0, 0, 0, 0, 0, 0
+    kernel_ms, primary_ms, paths, rays, wave_steps, primary_rays, list2_rays, segments, cands, boxes = [], [], 0, 0, 0, 0, 0, 0, 0, 0
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st.kernel_ms)   # HIP events around the tracing kernels (primary pass + megakernel), on the stream they ran on
@@ -164,6 +164,7 @@ def main():
         paths += st.paths
         rays += st.rays
         cands += st.candidates
+        boxes += st.box_tests
         wave_steps += st.wave_steps
         primary_rays += st.primary_rays + st.list2_rays   # every ray the primary pass resolved against a per-pixel list
         list2_rays += st.list2_rays
@@ -228,10 +229,13 @@ def main():
                          "rays_per_launch": scan_rays / max(segments, 1), "wave_steps_per_launch": wave_steps / args.steps / max(segments, 1),
                          "spheres": nsph, "shared_ordinate_tests": shared,
                          "basis": "algorithmic",
-                         "executed_frac": None if tree["nodes"] else (scan_rays * ((nsph - shared) * 15.0 + shared * 11.0 + 60.0)) / (m_ms * 1e-3) / PEAK_FP32_VALU,
-                         "scene_is_hit": ("sphere tree (%s): %d inner nodes, %d levels, %.1f exact sphere tests per ray instead of %d; the algorithmic "
+                         # tree walk: ~30 FLOP per ray-box test (6 differences, the margin, 6 slab products, min/max chains), 18 per exact sphere
+                         # test (a few of those are made by the primary pass, not the megakernel), 60 per ray: what active lanes compute, not issue slots
+                         "executed_frac": ((boxes / args.steps * 30.0 + cands / args.steps * 18.0 + scan_rays * 60.0) / (m_ms * 1e-3) / PEAK_FP32_VALU) if tree["nodes"]
+                                          else (scan_rays * ((nsph - shared) * 15.0 + shared * 11.0 + 60.0)) / (m_ms * 1e-3) / PEAK_FP32_VALU,
+                         "scene_is_hit": ("sphere tree (%s): %d inner nodes, %d levels, %.1f ray-box tests and %.1f exact sphere tests per ray instead of %d sphere tests; the algorithmic "
                                           "fractions count the tests of the reference's scan, most of which the tree never makes"
-                                          % ("walked in LDS" if nsph <= 512 else "walked in global memory", tree["nodes"], tree["depth"], cands / max(rays, 1), nsph))
+                                          % ("walked in LDS" if nsph <= 512 else "walked in global memory", tree["nodes"], tree["depth"], boxes / max(rays - primary_rays, 1), cands / max(rays, 1), nsph))
                                          if tree["nodes"] else "filter scan over all spheres + exact pass",
                          "render": render,
                          "note": "FP32 VALU roofline (no MFMA, not HBM-bound: SURVEY.md §8d) of the dominant kernel, pt_megakernel: "
@@ -239,8 +243,9 @@ def main():
                                  "for the device-counted rays the megakernel traces, over its HIP-event time in rank 0's render (`launches` "
                                  "segment launches; rocprofv3's average duration x launches agrees): an algorithmic-work rate, not hardware "
                                  "utilisation.  `executed_frac` prices what the filter scan executes per test (7 FMA + 1 compare = 15 FLOP; "
-                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words); null when `scene_is_hit` is the sphere tree "
-                                 "(scenes of 256 spheres and more: boxes select which spheres get the reference's exact test, same hits bit for bit).  `render.primary_rays` rays — the camera rays and "
+                                 "5 FMA + 1 compare = 11 for spheres in shared-ordinate mask words); when `scene_is_hit` is the sphere tree (scenes of 256 "
+                                 "spheres and more: boxes select which spheres get the reference's exact test, same hits bit for bit) it prices the device-counted "
+                                 "ray-box tests at 30 FLOP and exact sphere tests at 18.  `render.primary_rays` rays — the camera rays and "
                                  "(`of_which_second_bounce`) the rays scattered off each pixel's main diffuse sphere — never reach the "
                                  "megakernel: the primary pass resolves them against per-pixel candidate lists (same closest hit, bit for bit).  `render` prices the WHOLE render the same way — the reference's scan for "
                                  "every ray over the time of all tracing kernels — which is why its algorithmic_frac can pass 1.  "

@@ -124,16 +124,17 @@ typedef struct pt_stats {
     uint64_t paths;        /* camera samples traced                                  */
     uint64_t rays;         /* ray segments = closest-hit queries (Scene.is_hit calls)*/
     uint64_t sphere_tests; /* rays * n_spheres (what the reference's scan performs)  */
-    uint64_t candidates;   /* exact Sphere.is_hit evaluations after the LDS filter   */
+    uint64_t candidates;   /* exact Sphere.is_hit evaluations (after the LDS filter, in tree leaves, over candidate lists) */
     uint64_t not_unit;     /* lerp() directions failing illumination.zig:29          */
     uint64_t wave_steps;   /* ray steps executed by waves (rays / (64*wave_steps) = lane utilisation) */
-    uint64_t flush_iters;  /* wave iterations of the exact-test loop                 */
+    uint64_t flush_iters;  /* wave iterations of the exact-test loop / of the tree walk */
     double kernel_ms;      /* HIP-event time of the path-tracing kernels: primary pass + megakernel (of all segments, incl. their chunk sums, when segments > 1) */
     double total_ms;       /* kernel + chunk sums                                    */
     uint64_t segments;     /* megakernel launches the render took (PT_LIMIT_PARTIAL_BYTES, PT_LIMIT_PRIMARY_BYTES) */
     uint64_t primary_rays; /* of `rays`: camera rays whose closest hit came from their pixel's candidate list (primary pass), not from the scan */
     uint64_t list2_rays;   /* of `rays`: rays scattered off a pixel's main sphere whose closest hit came from that pixel's second-bounce list (primary pass) */
     double primary_ms;     /* of kernel_ms: the primary pass (candidate lists + camera rays + first radiance step), summed over the segments (0 beyond 64 segments) */
+    uint64_t box_tests;    /* ray-box tests of the sphere-tree walk (two per inner node a ray visits); 0 for scenes traced by the scan */
 } pt_stats;
 
 typedef struct ptgpu_ctx ptgpu_ctx;

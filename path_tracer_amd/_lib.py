@@ -72,7 +72,7 @@ class pt_stats(C.Structure):
                 ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("segments", C.c_uint64), ("primary_rays", C.c_uint64),
-                ("list2_rays", C.c_uint64), ("primary_ms", C.c_double)]
+                ("list2_rays", C.c_uint64), ("primary_ms", C.c_double), ("box_tests", C.c_uint64)]
 
 
 assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104

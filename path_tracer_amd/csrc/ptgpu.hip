@@ -90,7 +90,7 @@ constexpr uint32_t kHitMask = (1u << kTagShift) - 1u;
 constexpr uint32_t kDrawBits = 13;  // STATE2 packs (draws taken, second hit id) into the second half's .w: 13 + 19 bits
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_BOX_TESTS = 15, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
 // x / d for any u32 x without the ~35-instruction expansion of a run-time integer division: mulhi by a
 // host-computed magic number (the "branch-free" scheme: t = mulhi(x, M); q = (t + ((x - t) >> 1)) >> s).
@@ -464,7 +464,7 @@ struct TreeInLds {
 // them their next rays while the stragglers keep their place; they go on in the next ray step).  exit_at = 0: to the end.
 template <class Tree>
 __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t exit_at, uint32_t tid, V3 o, V3 d, float a, float t_min, float t_max,
-                                                  float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters) {
+                                                  float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters, uint32_t &n_boxes) {
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     // (a lane without a ray stays out — the caller gives it cur = kNone: its parked NaN direction would pass every box, min/max drop NaN operands)
@@ -500,6 +500,7 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
             float4 A, B, C; uint32_t c0, c1;
             T.node(cur, A, B, C, c0, c1);
             float n0, n1;
+            n_boxes += 2u;
             const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
             const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
             if (h0 && h1) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
     int t_hit = -1;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
-    uint32_t n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0; // per-lane counts (widened when the wave sums them)
+    uint32_t n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0, n_boxes = 0; // per-lane counts (widened when the wave sums them)
     uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
     unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
@@ -767,10 +768,10 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
             }
             if (TREE_LDS)
                 scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
-                                  t_hit, n_cands, n_flush_iters);
+                                  t_hit, n_cands, n_flush_iters, n_boxes);
             else
                 scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest, t_hit,
-                                  n_cands, n_flush_iters);
+                                  n_cands, n_flush_iters, n_boxes);
             tracing = tracing && t_cur == kNone && t_sp == 0u; // lanes still walking skip this step's shading and keep their ray
             closest = t_closest; hit = t_hit;
         } else
@@ -861,12 +862,13 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const
 #endif
     // ---- statistics ---------------------------------------------------------------
     const unsigned long long w_rays = wave_sum_u64(n_rays), w_cands = wave_sum_u64(n_cands), w_paths = wave_sum_u64(n_paths),
-                             w_not_unit = wave_sum_u64(n_not_unit);
+                             w_not_unit = wave_sum_u64(n_not_unit), w_boxes = TREE ? wave_sum_u64(n_boxes) : 0ull;
     if (lane == 0) {
         atomicAdd(&P.counters[CNT_RAYS], w_rays);
         atomicAdd(&P.counters[CNT_CANDS], w_cands);
         atomicAdd(&P.counters[CNT_PATHS], w_paths);
         if (w_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], w_not_unit);
+        if (TREE) atomicAdd(&P.counters[CNT_BOX_TESTS], w_boxes);
         atomicAdd(&P.counters[CNT_WAVE_STEPS], (unsigned long long)n_wave_steps);
         atomicAdd(&P.counters[CNT_FLUSH_ITERS], (unsigned long long)n_flush_iters);
     }
@@ -1653,13 +1655,13 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     float closest = t_max;
     int hit = -1;
     uint32_t n_cands = 0, n_iters = 0;
-    uint32_t sp = 0;
+    uint32_t sp = 0, n_boxes = 0;
     if (LDS) {
         uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone;
-        scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+        scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
     } else {
         uint32_t cur = live ? root : kTreeNone;
-        scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters);
+        scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
     }
     if (!live) return;
     float *w = out + (size_t)i * 8;
@@ -2384,6 +2386,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     ctx->stats.candidates = h[CNT_CANDS];
     ctx->stats.primary_rays = h[CNT_PRIMARY_RAYS];
     ctx->stats.list2_rays = h[CNT_LIST2_RAYS];
+    ctx->stats.box_tests = h[CNT_BOX_TESTS];
     ctx->stats.primary_ms = 0.0;
     if (primary && nseg <= kMaxTimedSegments) {
         for (uint32_t i = 0; i < nseg; ++i) {

@@ -288,7 +288,7 @@ extern "C" int ptgpu_multi_get_stats(const ptgpu_multi *m, int gpu, pt_stats *ou
     for (int g = 0; g < m->n; ++g) { // totals; times = the slowest GPU (they run side by side)
         const pt_stats &s = m->stats[g];
         t.paths += s.paths; t.rays += s.rays; t.sphere_tests += s.sphere_tests; t.candidates += s.candidates;
-        t.not_unit += s.not_unit; t.wave_steps += s.wave_steps; t.flush_iters += s.flush_iters; t.segments += s.segments; t.primary_rays += s.primary_rays; t.list2_rays += s.list2_rays;
+        t.not_unit += s.not_unit; t.wave_steps += s.wave_steps; t.flush_iters += s.flush_iters; t.segments += s.segments; t.primary_rays += s.primary_rays; t.list2_rays += s.list2_rays; t.box_tests += s.box_tests;
         if (s.primary_ms > t.primary_ms) t.primary_ms = s.primary_ms;
         if (s.kernel_ms > t.kernel_ms) t.kernel_ms = s.kernel_ms;
         if (s.total_ms > t.total_ms) t.total_ms = s.total_ms;

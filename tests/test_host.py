@@ -31,7 +31,7 @@ def test_pod_layouts_match_header():
     assert C.sizeof(_lib.pt_camera) == 76
     assert C.sizeof(_lib.pt_config) == 104
     assert _lib.pt_config.seed.offset == 24 and _lib.pt_config.tile_pixels.offset == 88
-    assert C.sizeof(_lib.pt_stats) == 104 and _lib.pt_stats.segments.offset == 72 and _lib.pt_stats.primary_ms.offset == 96
+    assert C.sizeof(_lib.pt_stats) == 112 and _lib.pt_stats.segments.offset == 72 and _lib.pt_stats.primary_ms.offset == 96 and _lib.pt_stats.box_tests.offset == 104
 
 
 def test_no_gpu_means_error_not_fallback():
