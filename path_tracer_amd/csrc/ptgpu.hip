@@ -439,7 +439,20 @@ struct TreeInGlobal {
 // In LDS (scenes of one tile whose tree has at most kTreeLdsNodes inner nodes and kTreeLdsStack + 1 levels): the whole tree
 // is staged once per workgroup — a walk step is then an LDS round trip instead of a trip to L1/L2 (the walk from global
 // memory waited on memory 64 % of its wave cycles on scene 21).  16-bit refs: bit 15 leaf | (count - 1) << 9 | first slot (< 512).
-constexpr uint32_t kTreeLdsNodes = 256, kTreeLdsStack = 16;
+// Capacity of the LDS copy and the occupancy it allows: 192 nodes + 12 stack entries = 24.75 KiB per workgroup, 6 per CU at 80 VGPRs
+// (measured against 256 nodes + 16 entries = 30 KiB, 5 per CU: 38.4 vs 39.8 ms per 256 samples of the headline frame; the walk waits
+// on LDS and on the record/table loads around it, a sixth wave hides some of that).  Median splits alone give at most 127 inner nodes
+// and 8 levels for 512 spheres with leaves of 4, so every one-tile scene has a tree that fits.
+#ifndef PT_TREE_LDS_NODES
+#define PT_TREE_LDS_NODES 192
+#endif
+#ifndef PT_TREE_LDS_STACK
+#define PT_TREE_LDS_STACK 12
+#endif
+#ifndef PT_TREE_LDS_WAVES
+#define PT_TREE_LDS_WAVES 6
+#endif
+constexpr uint32_t kTreeLdsNodes = PT_TREE_LDS_NODES, kTreeLdsStack = PT_TREE_LDS_STACK;
 struct TreeInLds {
     const float4 *boxes; const uint32_t *child; const float4 *tgeom; const uint16_t *tprim; uint16_t *stack;
     static constexpr uint32_t kLeafBit = 0x8000u, kNone = 0xffffu;
@@ -541,7 +554,7 @@ __device__ __forceinline__ void tree_stage_lds(const TreeNode *__restrict__ node
 // tables are read from global memory.  With MULTI_TILE the tree stays in global memory and s_mask is the lanes' stacks;
 // without (one-tile scenes) the whole tree is staged in LDS.
 template <bool DET, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
-__global__ __launch_bounds__(kBlock, PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
+__global__ __launch_bounds__(kBlock, (TREE && !MULTI_TILE) ? PT_TREE_LDS_WAVES : PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
     constexpr bool TREE_LDS = TREE && !MULTI_TILE;
     constexpr bool TABLES_LDS = !MULTI_TILE && !TREE;      // filter table, radii and materials of a one-tile scene
     __shared__ float4 s_filt[TREE ? 1 : kTile + kSub];      // (cx, cz, T, cy) filter records of the current tile
@@ -2049,8 +2062,8 @@ extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_
     // context with its previous scene intact (never half-updated).
     TreeBuild tree;
     bool with_tree = ctx->tree_min_spheres != 0u && n >= ctx->tree_min_spheres && tree_build(spheres, n, tree);
-    // a one-tile scene walks its tree in LDS: it has to fit there.  Median splits alone always do (leaves of two or more
-    // spheres: at most 255 inner nodes and 9 levels for 512 spheres).
+    // a one-tile scene walks its tree in LDS: it has to fit there.  Median splits alone always do (a range of more than 4 spheres
+    // is halved: seven halvings bring 512 spheres down to 4, so at most 128 leaves, 127 inner nodes and 8 levels).
     if (with_tree && n_pad <= (uint32_t)kTile && (tree.nodes.size() > kTreeLdsNodes || tree.depth > kTreeLdsStack + 1u)) {
         tree = TreeBuild();
         tree.sah = false;

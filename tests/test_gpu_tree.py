@@ -65,7 +65,7 @@ def test_tree_is_built_for_scenes_of_256_spheres_and_more(gpu):
     assert gpu.tree_info()["nodes"] == 0
     gpu.set_scene(host.Scene().setupScene(456, 21).spheres)                 # 488 spheres: one LDS tile, the tree is walked in LDS
     info = gpu.tree_info()
-    assert 488 // 4 - 1 <= info["nodes"] <= 256 and 8 <= info["depth"] <= 17
+    assert 488 // 4 - 1 <= info["nodes"] <= 192 and 8 <= info["depth"] <= 13
     big = host.Scene().sceneSynthetic(3000, 7).spheres
     gpu.set_scene(big)
     info = gpu.tree_info()
