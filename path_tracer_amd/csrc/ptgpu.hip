@@ -554,7 +554,10 @@ __device__ __forceinline__ void tree_stage_lds(const TreeNode *__restrict__ node
 // tables are read from global memory.  With MULTI_TILE the tree stays in global memory and s_mask is the lanes' stacks;
 // without (one-tile scenes) the whole tree is staged in LDS.
 template <bool DET, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
-__global__ __launch_bounds__(kBlock, (TREE && !MULTI_TILE) ? PT_TREE_LDS_WAVES : PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
+#ifndef PT_TREE_GLOBAL_WAVES
+#define PT_TREE_GLOBAL_WAVES 6 // 5 / 6 waves per SIMD: 37.4 / 35.6 ms per 256 samples of 3 000 spheres, 230.9 / 215.4 ms per frame of 100 000 (the walk waits on L2)
+#endif
+__global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES : PT_TREE_LDS_WAVES) : PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
     constexpr bool TREE_LDS = TREE && !MULTI_TILE;
     constexpr bool TABLES_LDS = !MULTI_TILE && !TREE;      // filter table, radii and materials of a one-tile scene
     __shared__ float4 s_filt[TREE ? 1 : kTile + kSub];      // (cx, cz, T, cy) filter records of the current tile
