@@ -296,6 +296,12 @@ int ptgpu_scene_info(const ptgpu_ctx *ctx, uint32_t *nspheres, uint32_t *shared_
 /* The sphere tree of the uploaded scene (PT_LIMIT_TREE_MIN_SPHERES): its inner nodes (0: the scene has none and is
  * traced by the scan) and its depth in levels. */
 int ptgpu_tree_info(const ptgpu_ctx *ctx, uint32_t *nodes, uint32_t *depth);
+/* Host-only self-check of the tree builder (no device, no context): builds the tree ptgpu_set_scene would build for these
+ * spheres (median_only != 0: without the surface-area heuristic) and counts structural violations — a sphere outside the box
+ * of an ancestor, missing from the leaves or listed twice, an oversized leaf.  *violations must come back 0.
+ * PT_ERR_UNSUPPORTED: no tree for this scene (non-finite spheres / too deep). */
+int ptgpu_debug_tree_check(const pt_sphere *spheres, uint32_t n, int median_only, uint32_t *nodes, uint32_t *depth, uint32_t *leaves,
+                           uint64_t *violations);
 int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
 const char *ptgpu_strerror(int status);
 int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */

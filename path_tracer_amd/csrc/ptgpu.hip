@@ -2029,6 +2029,63 @@ static bool tree_build(const pt_sphere *sp, uint32_t n, TreeBuild &T) {
     return T.depth <= kTreeStack;
 }
 
+// Host-only check of the builder (no device needed; tests/test_host.py): builds the tree ptgpu_set_scene would build and
+// walks it, counting what must never happen — a sphere (centre +- |radius|) sticking out of the box of any of its ancestors, a
+// sphere missing from the leaves or listed twice, a leaf beyond kTreeLeaf spheres, a leaf geometry that is not its sphere's.
+extern "C" int ptgpu_debug_tree_check(const pt_sphere *spheres, uint32_t n, int median_only, uint32_t *nodes, uint32_t *depth, uint32_t *leaves,
+                                      uint64_t *violations) {
+    if (!spheres || n == 0 || !violations) return PT_ERR_BAD_ARG;
+    TreeBuild T;
+    T.sah = !median_only;
+    if (!tree_build(spheres, n, T)) return PT_ERR_UNSUPPORTED;
+    uint64_t bad = 0;
+    uint32_t n_leaves = 0;
+    std::vector<uint8_t> seen(n, 0);
+    struct Item { uint32_t ref; TreeBox box; bool has_box; };
+    std::vector<Item> todo;
+    todo.push_back(Item{T.root, TreeBox(), false});
+    std::vector<TreeBox> chain; // (boxes are nested by construction only if every child box lies in its parent's: checked via the spheres)
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.ref & kTreeLeafBit) {
+            const uint32_t first = it.ref & 0x0fffffffu, cnt = ((it.ref >> 28) & 7u) + 1u;
+            n_leaves++;
+            if (cnt > kTreeLeaf || (size_t)first + cnt > T.tprim.size()) { bad++; continue; }
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t id = T.tprim[first + k];
+                if (id >= n || seen[id]) { bad++; continue; }
+                seen[id] = 1;
+                const pt_sphere &s = spheres[id];
+                const float4 g = T.tgeom[first + k];
+                if (memcmp(&g.x, &s.cx, 4) || memcmp(&g.y, &s.cy, 4) || memcmp(&g.z, &s.cz, 4) || memcmp(&g.w, &s.radius, 4)) bad++;
+                if (it.has_box) {
+                    const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
+                    for (int a = 0; a < 3; ++a)
+                        if (!((double)it.box.lo[a] <= (double)c[a] - r && (double)c[a] + r <= (double)it.box.hi[a])) { bad++; break; }
+                }
+            }
+        } else {
+            if (it.ref >= T.nodes.size()) { bad++; continue; }
+            const TreeNode &N = T.nodes[it.ref];
+            TreeBox b0, b1;
+            b0.lo[0] = N.a.x; b0.lo[1] = N.a.y; b0.lo[2] = N.a.z; b0.hi[0] = N.a.w; b0.hi[1] = N.b.x; b0.hi[2] = N.b.y;
+            b1.lo[0] = N.b.z; b1.lo[1] = N.b.w; b1.lo[2] = N.c.x; b1.hi[0] = N.c.y; b1.hi[1] = N.c.z; b1.hi[2] = N.c.w;
+            if (it.has_box) // a child's box inside its parent's: then "inside the leaf's box" above means inside every ancestor's
+                for (int a = 0; a < 3; ++a)
+                    if (b0.lo[a] < it.box.lo[a] || b1.lo[a] < it.box.lo[a] || b0.hi[a] > it.box.hi[a] || b1.hi[a] > it.box.hi[a]) { bad++; break; }
+            todo.push_back(Item{N.ch.x, b0, true});
+            todo.push_back(Item{N.ch.y, b1, true});
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) if (!seen[i]) bad++;
+    if (nodes) *nodes = (uint32_t)T.nodes.size();
+    if (depth) *depth = T.depth;
+    if (leaves) *leaves = n_leaves;
+    *violations = bad;
+    return PT_OK;
+}
+
 extern "C" int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_sphere *spheres, uint32_t n) {
     if (!ctx || !spheres || n == 0) return PT_ERR_BAD_ARG;
     for (uint32_t i = 0; i < n; ++i)

@@ -142,3 +142,36 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert L.ptgpu_destroy(None) == _lib.PT_ERR_BAD_ARG
     assert L.ptgpu_set_scene(None, None, 0) == _lib.PT_ERR_BAD_ARG
     assert L.ptgpu_get_stats(None, None) == _lib.PT_ERR_BAD_ARG
+
+
+def test_sphere_tree_builder_invariants():
+    """The builder behind ptgpu_set_scene, on the host alone: every sphere sits in exactly one leaf, inside the boxes of all its
+    ancestors (centre +- |radius|, the premise of the walk's conservativeness), leaves hold at most 4 spheres, depth within the
+    traversal stack; median splits alone stay within the LDS capacity for every one-tile scene."""
+    from path_tracer_amd import _lib, host
+    L = _lib.load()
+
+    def check(sp, median_only=0):
+        nodes, depth, leaves, bad = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(1)
+        rc = L.ptgpu_debug_tree_check(sp.ctypes.data, len(sp), median_only, C.byref(nodes), C.byref(depth), C.byref(leaves), C.byref(bad))
+        return rc, nodes.value, depth.value, leaves.value, bad.value
+
+    rng = np.random.default_rng(3)
+    scenes = [host.Scene().setupScene(456, k).spheres for k in (18, 19, 20, 21)] + [host.Scene().sceneSynthetic(n, 2).spheres for n in (1, 4, 5, 300, 3000, 100000)]
+    for trial in range(30):
+        n = int(rng.choice([2, 9, 77, 512, 2000]))
+        sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
+        spread = float(rng.choice([0.0, 1.0, 50.0]))
+        sp["cx"], sp["cy"], sp["cz"] = 1.0e4 * (trial % 3) + rng.normal(0, spread, n), np.round(rng.normal(0, spread, n)), rng.normal(0, spread, n)
+        sp["radius"] = rng.choice([1e-3, 0.2, 3.0, 5000.0, -0.7], n)
+        scenes.append(sp)
+    for sp in scenes:
+        for median_only in (0, 1):
+            rc, nodes, depth, leaves, bad = check(sp, median_only)
+            assert rc == 0 and bad == 0
+            assert depth <= 24 and leaves >= (len(sp) + 3) // 4 and (nodes == leaves - 1 or len(sp) <= 4)
+            if median_only and len(sp) <= 512:
+                assert nodes <= 127 and depth <= 8          # what the LDS copy (192 nodes, 13 levels) relies on
+    bad_scene = scenes[7].copy()
+    bad_scene["cy"][3] = np.inf
+    assert check(bad_scene)[0] == _lib.PT_ERR_UNSUPPORTED

@@ -95,6 +95,7 @@ pub const PT_LIMIT_PRIMARY_BOUNCES: c_int = 2; // 1: camera rays only, 2 (defaul
 pub const PT_LIMIT_TREE_MIN_SPHERES: c_int = 3; // scenes of at least this many spheres (default 256; 0: never) are traced through a sphere tree; set before ptgpu_set_scene
 pub extern fn ptgpu_set_limit(ctx: *PtCtx, which: c_int, value: u64) c_int;
 pub extern fn ptgpu_tree_info(ctx: *const PtCtx, nodes: ?*u32, depth: ?*u32) c_int;
+pub extern fn ptgpu_debug_tree_check(spheres: [*]const PtSphere, n: u32, median_only: c_int, nodes: ?*u32, depth: ?*u32, leaves: ?*u32, violations: *u64) c_int; // host-only builder self-check
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
 pub extern fn ptgpu_abi_version() u32;
 
