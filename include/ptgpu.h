@@ -306,7 +306,7 @@ int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
 const char *ptgpu_strerror(int status);
 int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */
 int ptgpu_device_info(const ptgpu_ctx *ctx, int *compute_units, int *clock_khz, char *arch, size_t arch_len);
-uint32_t ptgpu_abi_version(void);
+uint32_t ptgpu_abi_version(void); /* 2 (round 2: pt_stats is 112 bytes; a host built against 1 must be rebuilt) */
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@
 
 using namespace ptdev;
 
-#define PT_ABI_VERSION 1u
+#define PT_ABI_VERSION 2u // 2: pt_stats grew to 112 bytes (segments ... box_tests); limits, tree and no-allocation entry points added
 
 // ---------------------------------------------------------------------------
 // kernel parameters

@@ -20,7 +20,7 @@ def test_libptgpu_exports_every_declared_symbol():
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ptgpu_abi_version() == 1
+    assert L.ptgpu_abi_version() == 2
     assert _lib.strerror(_lib.PT_ERR_DIRECTION_NOT_UNIT) == "DirectionIsNotUnitVector"
     assert _lib.strerror(_lib.PT_ERR_SCENE_NOT_AVAILABLE) == "SceneNotAvailable"
 
