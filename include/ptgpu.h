@@ -106,7 +106,20 @@ typedef struct pt_config {
     uint32_t tile_pixels;                   /* tile split: pixels per tile, 0 = off */
     uint32_t tile_count, tile_index;        /* tile t of the range belongs to owner t % tile_count */
     uint32_t illumination;                  /* PT_ILLUM_*: which illumination.zig function colours a sample */
+    uint32_t sampler;                       /* PT_SAMPLER_*: how unit-disk / unit-ball vectors are drawn (mode 0 only) */
+    uint32_t reserved_;                     /* 0 */
 } pt_config;
+
+/* The reference draws its lens and scatter vectors with rejection loops (camera.zig:113-120: the unit disk;
+ * material.zig:27-34: [0,1)^3 kept inside the unit ball, i.e. the POSITIVE OCTANT of the ball).
+ *   PT_SAMPLER_REJECTION (default)  those loops, try by try, as the reference runs them;
+ *   PT_SAMPLER_DIRECT               NOT in the reference: the same two distributions drawn without a loop from one
+ *                                   try's worth of draws (sqrt(xi0) (cos, sin)(2 pi xi1); a uniform
+ *                                   direction of the octant times xi2^(1/3)), in f32 operations the oracle repeats
+ *                                   bit for bit.  Other numbers per path, the same image in distribution (the tests
+ *                                   show the equivalence); a wave no longer waits for its slowest lane's retries.
+ * Deterministic mode ignores the field (every draw is 0.5 and goes through the reference's expressions). */
+enum { PT_SAMPLER_REJECTION = 0, PT_SAMPLER_DIRECT = 1 };
 
 /* The reference has three per-sample colour functions; render() calls radiance and keeps the
  * other two as commented-out alternatives (renderers/ppm_image.zig:64-66).  The first-hit ones
@@ -135,6 +148,9 @@ typedef struct pt_stats {
     uint64_t list2_rays;   /* of `rays`: rays scattered off a pixel's main sphere whose closest hit came from that pixel's second-bounce list (primary pass) */
     double primary_ms;     /* of kernel_ms: the primary pass (candidate lists + camera rays + first radiance step), summed over the segments (0 beyond 64 segments) */
     uint64_t box_tests;    /* ray-box tests of the sphere-tree walk (two per inner node a ray visits); 0 for scenes traced by the scan */
+    double lists_ms;       /* of primary_ms: the kernels that build the per-pixel candidate lists (pt_list_prep, pt_primary_lists) */
+    double megakernel_ms;  /* of kernel_ms: pt_megakernel alone, summed over the segments (0 beyond 64 segments) */
+    uint64_t primary_candidates; /* of `candidates`: exact Sphere.is_hit evaluations made by the primary pass over its lists */
 } pt_stats;
 
 typedef struct ptgpu_ctx ptgpu_ctx;
@@ -168,9 +184,11 @@ int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum
  * same arguments, same result bit for bit, but the kernels' working memory (counters, hit-id stack,
  * chunk partial sums) is a static device array of ptgpu_noalloc_scratch_bytes() = 128 MiB per GPU
  * inside the library instead of hipMalloc'ed buffers, and the call performs no hipMalloc / hipFree.
- * The hit-id stack (rebounds x resident threads x 4 B) must fit, else PT_ERR_SCRATCH_LIMIT (depth 50
- * takes 62.5 MiB; up to depth 102 fits); what remains holds the chunk partials, in as many segments
- * as it takes (chunk = 0 needs none).  The scratch is shared by every context on the same GPU and
+ * The hit-id stack (rebounds x resident threads x 4 B) must fit, else PT_ERR_SCRATCH_LIMIT: scenes traced by the
+ * scan keep 327 680 threads resident (5 workgroups per CU: 1.25 MiB per bounce, depth 50 = 62.5 MiB, up to depth 102
+ * fits), scenes traced through the sphere tree (256 spheres and more) 393 216 (6 per CU: 1.5 MiB per bounce, depth
+ * 50 = 75 MiB, up to depth 85); what remains holds the chunk partials, in as many segments as it takes (chunk = 0
+ * needs none).  The scratch is shared by every context on the same GPU and
  * keeps the last call's contents: calls that overlap on one GPU race — serialise them. */
 int ptgpu_render_sum_device_noalloc(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_sum, void *stream);
 uint64_t ptgpu_noalloc_scratch_bytes(void);
@@ -219,8 +237,10 @@ enum {
     PT_FN_FILTER_BIT = 10, /* the LDS filter's verdict for one (ray, sphere) pair: in: o,d,c,r (10)  out: candidate bit,
                               reference discriminant of sphere.zig:74, candidate bit of the shared-ordinate form of the
                               test (3).  Invariant: discriminant >= 0 => both bits == 1 */
-    PT_FN_SCENE_HIT_TREE = 11 /* scene.zig:96 through the sphere tree of large scenes (PT_LIMIT_TREE_MIN_SPHERES): in/out as
+    PT_FN_SCENE_HIT_TREE = 11, /* scene.zig:96 through the sphere tree of large scenes (PT_LIMIT_TREE_MIN_SPHERES): in/out as
                               PT_FN_SCENE_HIT; PT_ERR_UNSUPPORTED when the uploaded scene has no tree */
+    PT_FN_SAMPLE_DISK = 12, /* camera.zig:113-120 or its direct equivalent: in: sampler (PT_SAMPLER_*), xi[16] (17)  out: p, n_used (4) */
+    PT_FN_SAMPLE_BALL = 13  /* material.zig:27-34 or its direct equivalent: in: sampler, xi[16] (17)                  out: p, n_used (4) */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);
@@ -266,13 +286,16 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * pixels, one kernel launch each, through the same buffer; the result is bit-identical (a pixel's
  * partial sums are always added in chunk order), pt_stats.segments tells how many launches it took.
  *
- * PT_LIMIT_PRIMARY_BYTES (default 96 GiB; 0 switches the primary pass off): upper bound of the device
+ * PT_LIMIT_PRIMARY_BYTES (default ~0 = automatic; 0 switches the primary pass off): upper bound of the device
  * buffer of the primary pass: one 32-byte record per path of a launch plus 176 B of candidate lists per
- * pixel.  The primary pass traces every camera ray against the few spheres its pixel's rays can reach
+ * pixel.  Automatic = half of the device memory that is free when the render starts (hipMemGetInfo; what the context
+ * already holds for the pass counts as free), at most 96 GiB — a host that shares the GPU with other allocators keeps
+ * room.  The primary pass traces every camera ray against the few spheres its pixel's rays can reach
  * (a conservative per-pixel list built per launch) and shades the first hit; the megakernel continues the
  * paths from the records, so its scan over all spheres only serves scattered rays.  Same closest hits,
  * same draws, same sums: results do not depend on this limit, only segments and speed do.  The buffer is
- * allocated at the size a render needs, not at the limit.  ptgpu_render_sum_device_noalloc never runs the
+ * allocated at the size a render needs, not at the limit, and kept for the next render; lowering the limit below
+ * the held size frees it at once, ptgpu_trim frees every work buffer.  ptgpu_render_sum_device_noalloc never runs the
  * primary pass (its records would not fit the static scratch).
  *
  * PT_LIMIT_PRIMARY_BOUNCES (1 or 2, default 2): 2 lets the primary pass also trace the ray the sphere a pixel mainly
@@ -288,6 +311,11 @@ int ptgpu_multi_last_rccl_error(const ptgpu_multi *m);          /* raw ncclResul
  * spheres), keep the scan. */
 enum { PT_LIMIT_PARTIAL_BYTES = 0, PT_LIMIT_PRIMARY_BYTES = 1, PT_LIMIT_PRIMARY_BOUNCES = 2, PT_LIMIT_TREE_MIN_SPHERES = 3 };
 int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value);
+/* Device memory the context holds besides the scene tables (records and lists of the primary pass, chunk partials,
+ * hit-id stack, staging images): grown on demand by the renders, kept between them.  ptgpu_trim gives all of it back
+ * (the next render allocates again what it needs); ptgpu_work_bytes reports the bytes held now. */
+int ptgpu_trim(ptgpu_ctx *ctx);
+uint64_t ptgpu_work_bytes(const ptgpu_ctx *ctx);
 
 /* Diagnostics. */
 /* The uploaded scene: its sphere count, and how many of them sit in mask words (32 consecutive spheres) that share
@@ -306,7 +334,7 @@ int ptgpu_get_stats(const ptgpu_ctx *ctx, pt_stats *out);
 const char *ptgpu_strerror(int status);
 int ptgpu_last_hip_error(const ptgpu_ctx *ctx); /* raw hipError_t of the last PT_ERR_HIP */
 int ptgpu_device_info(const ptgpu_ctx *ctx, int *compute_units, int *clock_khz, char *arch, size_t arch_len);
-uint32_t ptgpu_abi_version(void); /* 2 (round 2: pt_stats is 112 bytes; a host built against 1 must be rebuilt) */
+uint32_t ptgpu_abi_version(void); /* 3 (round 3: pt_config is 112 bytes (sampler), pt_stats 136; a host built against 2 must be rebuilt) */
 
 #ifdef __cplusplus
 }

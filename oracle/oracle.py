@@ -33,7 +33,10 @@ class Config(C.Structure):
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
                 ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
                 ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
-                ("illumination", C.c_uint32)]
+                ("illumination", C.c_uint32), ("sampler", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+SAMPLER_REJECTION, SAMPLER_DIRECT = 0, 1   # pt_oracle.h
 
 
 class Image(C.Structure):
@@ -151,6 +154,11 @@ def lib():
         L.orc_scatter.argtypes = [C.c_void_p, fp, fp, fp, fp, C.c_uint32, C.POINTER(C.c_uint32), fp, fp, fp]
         L.orc_scatter.restype = None
         L.orc_lerp.argtypes = [fp, fp, fp, fp]
+        for name in ("orc_sample_disk", "orc_sample_ball"):
+            getattr(L, name).argtypes = [C.c_uint32, fp, C.c_uint32, C.POINTER(C.c_uint32), fp]
+            getattr(L, name).restype = None
+        L.orc_sample_batch.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_sample_batch.restype = None
         _lib = L
     return _lib
 
@@ -202,7 +210,7 @@ def image_new(width, aspect=ASPECT_16_9, max_px_value=255):
 
 def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed=0, t_min=0.1, t_max=1000.0,
                 idx_start=0, idx_stop=None, sample_start=0, sample_stop=0, chunk=0, tile_pixels=0, tile_count=1,
-                tile_index=0, illumination=0):
+                tile_index=0, illumination=0, sampler=0):
     """RayTracerConfig as main.zig:85-91 sets it, plus the work range."""
     cfg = Config()
     cfg.width, cfg.height = img.width, img.height
@@ -217,6 +225,7 @@ def make_config(img, subpixels=4, rays_per_subsample=1, rebounds=6, mode=0, seed
     cfg.max_px_value = img.max_px_value
     cfg.tile_pixels, cfg.tile_count, cfg.tile_index = tile_pixels, tile_count, tile_index
     cfg.illumination = illumination
+    cfg.sampler = sampler
     return cfg
 
 
@@ -238,6 +247,14 @@ def render_sum_zig(spheres, cam, cfg, rng):
     rc = lib().orc_render_sum_zig(sp.ctypes.data, len(sp), C.byref(cam), C.byref(cfg), C.byref(rng), out.ctypes.data,
                                   C.byref(st))
     return rc, out, st
+
+
+def sample_batch(which, sampler, xi):
+    """which: "disk" | "ball"; xi: (n, stride) float32 draws -> (n, 4) float32: the vector and the draws it consumed."""
+    xi = np.ascontiguousarray(xi, dtype=np.float32)
+    out = np.zeros((xi.shape[0], 4), dtype=np.float32)
+    lib().orc_sample_batch(0 if which == "disk" else 1, int(sampler), xi.ctypes.data, xi.shape[0], xi.shape[1], out.ctypes.data)
+    return out
 
 
 def resolve_mean(cfg, rgb_sum):

@@ -149,6 +149,7 @@ typedef struct rng_t {
     uint32_t key[2], ctr[4], buf[4], n; /* philox path stream: draw n = word n&3 of block n>>2 */
     orc_zigrng *z;
     const float *xi; uint32_t n_xi;     /* array */
+    int direct;                         /* orc_config.sampler == ORC_SAMPLER_DIRECT (never in deterministic mode) */
 } rng_t;
 
 static float rng_float(rng_t *r) {
@@ -183,6 +184,66 @@ static void rng_philox_path(rng_t *r, uint64_t seed, uint32_t pixel, uint32_t sa
  * draw (probability < 1e-80 for the ball, never observed): a bound every wave
  * reaches, not a change of distribution. */
 #define ORC_MAX_TRIES 256
+
+/* ---- ORC_SAMPLER_DIRECT: the same two distributions without the rejection loops --------------
+ * NOT in the reference: an opt-in of this build (orc_config.sampler), restated here so that the GPU's direct samplers
+ * have an oracle.  Plain f32 multiplies, adds, one sqrtf and integer bit operations only — no libm sin/cos/cbrt — so
+ * that gcc and the GPU evaluate the same IEEE operations and agree bit for bit.  One "try" worth of draws each. */
+/* sin and cos of f * pi/2, f in [0,1): folded to [0, pi/4], Taylor polynomials (errors < 3e-8 before rounding) */
+static void sincos_quarter(float f, float *s_out, float *c_out) {
+    const int swap = f > 0.5f;
+    const float g = swap ? 1.0f - f : f;            /* exact */
+    const float th = g * 1.57079632679489661923f;
+    const float t2 = th * th;
+    float sp = 2.75573192239858906526e-6f;          /* 1/9! */
+    sp = sp * t2 + -1.98412698412698412698e-4f;     /* -1/7! */
+    sp = sp * t2 + 8.33333333333333333333e-3f;      /* 1/5! */
+    sp = sp * t2 + -1.66666666666666666667e-1f;     /* -1/3! */
+    sp = sp * t2 + 1.0f;
+    const float sn = th * sp;
+    float cp = 2.48015873015873015873e-5f;          /* 1/8! */
+    cp = cp * t2 + -1.38888888888888888889e-3f;     /* -1/6! */
+    cp = cp * t2 + 4.16666666666666666667e-2f;      /* 1/4! */
+    cp = cp * t2 + -0.5f;
+    cp = cp * t2 + 1.0f;
+    *s_out = swap ? cp : sn;
+    *c_out = swap ? sn : cp;
+}
+/* x^(1/3), x in [0,1): x * r^2 with r = x^(-1/3) from the exponent trick and three Newton steps r <- r (4 - x r^3) / 3
+ * (relative error < 5e-7) */
+static float cbrt_unit(float x) {
+    uint32_t i;
+    memcpy(&i, &x, 4);
+    i = 0x54a21d2au - i / 3u;
+    float r;
+    memcpy(&r, &i, 4);
+    const float third = 1.0f / 3.0f;
+    for (int k = 0; k < 3; k++) {
+        const float r3 = (r * r) * r;
+        r = (r * (4.0f - x * r3)) * third;
+    }
+    return (x == 0.0f) ? 0.0f : x * (r * r);
+}
+/* uniform in the unit disk (camera.zig:113-120's distribution): sqrt(xi0) * (cos, sin)(2 pi xi1) */
+static vec3 direct_vector_in_unit_disk(float xi0, float xi1) {
+    const float q = xi1 * 4.0f;                      /* exact */
+    const uint32_t k = (uint32_t)q;                  /* quadrant 0..3 */
+    float s, c;
+    sincos_quarter(q - (float)k, &s, &c);
+    const float cx = (k == 0u) ? c : (k == 1u) ? -s : (k == 2u) ? -c : s;
+    const float sy = (k == 0u) ? s : (k == 1u) ? c : (k == 2u) ? -s : -c;
+    const float rr = sqrtf(xi0);
+    return v3(rr * cx, rr * sy, 0.0f);
+}
+/* uniform in the positive octant of the unit ball (material.zig:27-34's distribution, [0,1)^3 kept inside the ball):
+ * direction with z = xi0 uniform (equal areas), azimuth xi1 * pi/2, radius xi2^(1/3) */
+static vec3 direct_vector_in_unit_sphere(float xi0, float xi1, float xi2) {
+    float s, c;
+    sincos_quarter(xi1, &s, &c);
+    const float sxy = sqrtf(1.0f - xi0 * xi0);
+    const float rho = cbrt_unit(xi2);
+    return v3(rho * (sxy * c), rho * (sxy * s), rho * xi0);
+}
 
 /* ------------------------------------------------------------------------ */
 /* sphere.zig / scene.zig / material.zig / camera.zig / illumination.zig      */
@@ -235,6 +296,11 @@ static int scene_is_hit(const orc_sphere *sp, uint32_t n, ray_t ray, float t_min
 /* material.zig:27-34 — note [0,1)^3: positive octant of the unit ball. */
 static vec3 random_vector_in_unit_sphere(rng_t *r) {
     vec3 p = v3(0, 0, 0);
+    if (r->direct) {
+        rng_reserve(r, 3);
+        const float x = rng_float(r), y = rng_float(r), z = rng_float(r);
+        return direct_vector_in_unit_sphere(x, y, z);
+    }
     for (int tries = 0; tries < ORC_MAX_TRIES; tries++) {
         rng_reserve(r, 3);
         const float x = rng_float(r), y = rng_float(r), z = rng_float(r);
@@ -246,6 +312,11 @@ static vec3 random_vector_in_unit_sphere(rng_t *r) {
 /* camera.zig:113-120 */
 static vec3 random_vector_in_unit_disk(rng_t *r) {
     vec3 p = v3(0, 0, 0);
+    if (r->direct) {
+        rng_reserve(r, 2);
+        const float x = rng_float(r), y = rng_float(r);
+        return direct_vector_in_unit_disk(x, y);
+    }
     for (int tries = 0; tries < ORC_MAX_TRIES; tries++) {
         rng_reserve(r, 2);
         const float x = 2.0f * rng_float(r) - 1.0f;
@@ -504,7 +575,7 @@ static int render_range(const orc_sphere *sp, uint32_t n, const orc_camera *cam,
             for (uint32_t s = c0; s < c1; s++) {
                 rng_t r;
                 if (cfg->mode == ORC_MODE_DETERMINISTIC) { memset(&r, 0, sizeof r); r.kind = RNG_CONST; }
-                else rng_philox_path(&r, cfg->seed, idx, s);
+                else { rng_philox_path(&r, cfg->seed, idx, s); r.direct = cfg->sampler == ORC_SAMPLER_DIRECT; }
                 vec3 color_sample;
                 const int rc = trace_sample(&tc, cam, cfg, idx, &r, &r, 0, &color_sample);
                 paths++;
@@ -580,7 +651,7 @@ int orc_sample_radiance(const orc_sphere *sp, uint32_t n, const orc_camera *cam,
     trace_ctx_init(&tc, sp, n, cfg);
     rng_t r;
     if (cfg->mode == ORC_MODE_DETERMINISTIC) { memset(&r, 0, sizeof r); r.kind = RNG_CONST; }
-    else rng_philox_path(&r, cfg->seed, idx, sample);
+    else { rng_philox_path(&r, cfg->seed, idx, sample); r.direct = cfg->sampler == ORC_SAMPLER_DIRECT; }
     vec3 c = v3(0, 0, 0);
     const int rc = trace_sample(&tc, cam, cfg, idx, &r, &r, iterative, &c);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
@@ -598,6 +669,7 @@ int orc_render_sum_zig(const orc_sphere *sp, uint32_t n, const orc_camera *cam, 
     rng_t r_cam, r_mat;
     memset(&r_cam, 0, sizeof r_cam); r_cam.kind = RNG_ZIG; r_cam.z = zr;
     memset(&r_mat, 0, sizeof r_mat); r_mat.kind = RNG_ZIG; r_mat.z = &mat_state;
+    r_cam.direct = r_mat.direct = cfg->sampler == ORC_SAMPLER_DIRECT;
     uint64_t paths = 0;
     int rc_all = ORC_OK;
     for (uint32_t idx = cfg->idx_start; idx < cfg->idx_stop; idx++) {
@@ -872,6 +944,28 @@ int orc_scene_hit(const orc_sphere *sp, uint32_t n, const float o[3], const floa
     if (!scene_is_hit(sp, n, ray, t_min, t_max, &h)) return -1;
     *t = h.t; p[0] = h.p.x; p[1] = h.p.y; p[2] = h.p.z; nrm[0] = h.n.x; nrm[1] = h.n.y; nrm[2] = h.n.z;
     return h.index;
+}
+/* the two samplers on caller-supplied draws: sampler = ORC_SAMPLER_REJECTION (the reference's loops) or ORC_SAMPLER_DIRECT */
+void orc_sample_disk(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]) {
+    rng_t r; rng_array(&r, xi, n_xi); r.direct = sampler == ORC_SAMPLER_DIRECT;
+    const vec3 p = random_vector_in_unit_disk(&r);
+    if (n_used) *n_used = r.n;
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+void orc_sample_ball(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]) {
+    rng_t r; rng_array(&r, xi, n_xi); r.direct = sampler == ORC_SAMPLER_DIRECT;
+    const vec3 p = random_vector_in_unit_sphere(&r);
+    if (n_used) *n_used = r.n;
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+/* n records of `stride` draws each -> (p, n_used) per record; which: 0 disk, 1 ball */
+void orc_sample_batch(int which, uint32_t sampler, const float *xi, uint32_t n, uint32_t stride, float *out4) {
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t used = 0;
+        if (which == 0) orc_sample_disk(sampler, xi + (size_t)i * stride, stride, &used, out4 + 4 * (size_t)i);
+        else orc_sample_ball(sampler, xi + (size_t)i * stride, stride, &used, out4 + 4 * (size_t)i);
+        out4[4 * (size_t)i + 3] = (float)used;
+    }
 }
 void orc_reflect(const float d[3], const float n[3], float out[3]) {
     vec3 r = reflect(v3(d[0], d[1], d[2]), v3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;

@@ -58,7 +58,14 @@ typedef struct orc_config {
     uint32_t max_px_value;
     uint32_t tile_pixels, tile_count, tile_index; /* interleaved tile ownership (multi-GPU split) */
     uint32_t illumination; /* 0 radiance (illumination.zig:76), 1 colorNormal (:42), 2 colorAlbedo (:60) */
+    uint32_t sampler;      /* ORC_SAMPLER_*: how the unit-disk and unit-ball vectors are drawn (ignored in deterministic mode) */
+    uint32_t reserved_;    /* 0 */
 } orc_config;
+
+/* ORC_SAMPLER_REJECTION: the reference's rejection loops (camera.zig:113-120, material.zig:27-34).
+ * ORC_SAMPLER_DIRECT: NOT in the reference — the same two distributions drawn without a loop,
+ * in operations gcc and the GPU evaluate identically; an opt-in whose statistical equivalence the tests show. */
+enum { ORC_SAMPLER_REJECTION = 0, ORC_SAMPLER_DIRECT = 1 };
 
 typedef struct orc_image {
     float aspect_ratio;
@@ -125,6 +132,9 @@ int orc_sphere_hit(const orc_sphere *sp, const float o[3], const float d[3], flo
                    float *t, float p[3], float n[3]);                        /* sphere.zig:63-103 */
 int orc_scene_hit(const orc_sphere *sp, uint32_t n, const float o[3], const float d[3], float t_min, float t_max,
                   float *t, float p[3], float nrm[3]);                       /* scene.zig:96-110; returns index or -1 */
+void orc_sample_disk(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]); /* camera.zig:113-120 / direct */
+void orc_sample_ball(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]); /* material.zig:27-34 / direct */
+void orc_sample_batch(int which /* 0 disk, 1 ball */, uint32_t sampler, const float *xi, uint32_t n, uint32_t stride, float *out4 /* p, n_used */);
 void orc_reflect(const float d[3], const float n[3], float out[3]);          /* material.zig:59-65 */
 int orc_refract(const float d[3], const float n[3], float n1_over_n2, float out[3]); /* material.zig:98-116; 0 = null */
 float orc_schlick(float cosine, float refraction_index);                     /* material.zig:120-124 */

@@ -29,18 +29,21 @@ PT_LIMIT_PRIMARY_BYTES = 1
 PT_LIMIT_PRIMARY_BOUNCES = 2
 PT_LIMIT_TREE_MIN_SPHERES = 3
 PT_TREE_MIN_SPHERES_DEFAULT = 256      # the library's default
-PT_PRIMARY_BYTES_DEFAULT = 96 << 30   # the library's default for PT_LIMIT_PRIMARY_BYTES
+PT_PRIMARY_BYTES_AUTO = (1 << 64) - 1  # the library's default for PT_LIMIT_PRIMARY_BYTES: sized per render from hipMemGetInfo (at most 96 GiB)
+PT_PRIMARY_BYTES_DEFAULT = PT_PRIMARY_BYTES_AUTO
 PT_SPLIT_TILES, PT_SPLIT_SAMPLES = 0, 1
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC = 0, 1, 2
 PT_ILLUM_RADIANCE, PT_ILLUM_NORMAL, PT_ILLUM_ALBEDO = 0, 1, 2
+PT_SAMPLER_REJECTION, PT_SAMPLER_DIRECT = 0, 1
 
 (PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
- PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT, PT_FN_SCENE_HIT_TREE) = range(12)
+ PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT, PT_FN_SCENE_HIT_TREE, PT_FN_SAMPLE_DISK,
+ PT_FN_SAMPLE_BALL) = range(14)
 FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
     PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
     PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8),
-    PT_FN_FILTER_BIT: (10, 3), PT_FN_SCENE_HIT_TREE: (6, 8)}
+    PT_FN_FILTER_BIT: (10, 3), PT_FN_SCENE_HIT_TREE: (6, 8), PT_FN_SAMPLE_DISK: (17, 4), PT_FN_SAMPLE_BALL: (17, 4)}
 
 # pt_sphere: 36 bytes
 SPHERE_DTYPE = np.dtype(
@@ -64,7 +67,7 @@ class pt_config(C.Structure):
                 ("sample_start", C.c_uint32), ("sample_stop", C.c_uint32),
                 ("chunk", C.c_uint32), ("max_px_value", C.c_uint32),
                 ("tile_pixels", C.c_uint32), ("tile_count", C.c_uint32), ("tile_index", C.c_uint32),
-                ("illumination", C.c_uint32)]
+                ("illumination", C.c_uint32), ("sampler", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class pt_stats(C.Structure):
@@ -72,14 +75,15 @@ class pt_stats(C.Structure):
                 ("candidates", C.c_uint64), ("not_unit", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("flush_iters", C.c_uint64), ("kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("segments", C.c_uint64), ("primary_rays", C.c_uint64),
-                ("list2_rays", C.c_uint64), ("primary_ms", C.c_double), ("box_tests", C.c_uint64)]
+                ("list2_rays", C.c_uint64), ("primary_ms", C.c_double), ("box_tests", C.c_uint64),
+                ("lists_ms", C.c_double), ("megakernel_ms", C.c_double), ("primary_candidates", C.c_uint64)]
 
 
-assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 104
+assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 112 and C.sizeof(pt_stats) == 136
 
 # every symbol include/ptgpu.h declares
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
-           "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit",
+           "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit", "ptgpu_trim", "ptgpu_work_bytes",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
            "ptgpu_debug_eval", "ptgpu_get_stats", "ptgpu_scene_info", "ptgpu_tree_info", "ptgpu_debug_tree_check", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
            "ptgpu_abi_version",
@@ -117,6 +121,9 @@ def load():
     L.ptgpu_render_sum_device_noalloc.argtypes = [vp, C.POINTER(pt_config), vp, vp]
     L.ptgpu_noalloc_scratch_bytes.restype = C.c_uint64
     L.ptgpu_set_limit.argtypes = [vp, C.c_int, C.c_uint64]
+    L.ptgpu_trim.argtypes = [vp]
+    L.ptgpu_work_bytes.argtypes = [vp]
+    L.ptgpu_work_bytes.restype = C.c_uint64
     L.ptgpu_render_sum_host.argtypes = [vp, C.POINTER(pt_config), vp]
     L.ptgpu_render_mean_host.argtypes = [vp, C.POINTER(pt_config), vp]
     L.ptgpu_resolve_device.argtypes = [vp, C.POINTER(pt_config), vp, vp, vp, vp]

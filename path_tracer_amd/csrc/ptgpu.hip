@@ -36,7 +36,7 @@
 
 using namespace ptdev;
 
-#define PT_ABI_VERSION 2u // 2: pt_stats grew to 112 bytes (segments ... box_tests); limits, tree and no-allocation entry points added
+#define PT_ABI_VERSION 3u // 3: pt_config grew to 112 bytes (sampler), pt_stats to 136 (lists_ms, megakernel_ms, primary_candidates); 2: pt_stats 112 bytes, limits, tree, no-allocation entry point
 
 // ---------------------------------------------------------------------------
 // kernel parameters
@@ -90,7 +90,7 @@ constexpr uint32_t kHitMask = (1u << kTagShift) - 1u;
 constexpr uint32_t kDrawBits = 13;  // STATE2 packs (draws taken, second hit id) into the second half's .w: 13 + 19 bits
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_BOX_TESTS = 15, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_BOX_TESTS = 15, CNT_PRIMARY_CANDS = 20, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
 
 // x / d for any u32 x without the ~35-instruction expansion of a run-time integer division: mulhi by a
 // host-computed magic number (the "branch-free" scheme: t = mulhi(x, M); q = (t + ((x - t) >> 1)) >> s).
@@ -553,11 +553,15 @@ __device__ __forceinline__ void tree_stage_lds(const TreeNode *__restrict__ node
 // TREE: Scene.is_hit walks the sphere tree instead of scanning; no filter table, no barriers in the ray loop; the sphere
 // tables are read from global memory.  With MULTI_TILE the tree stays in global memory and s_mask is the lanes' stacks;
 // without (one-tile scenes) the whole tree is staged in LDS.
-template <bool DET, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
+// MODE: 0 stochastic with the reference's rejection loops, 1 deterministic (every draw 0.5), 2 stochastic with the direct
+// samplers (pt_config.sampler = PT_SAMPLER_DIRECT)
+enum { kModeRejection = 0, kModeDet = 1, kModeDirect = 2 };
+template <int MODE, bool MULTI_TILE, bool PRIMARY, bool TREE = false>
 #ifndef PT_TREE_GLOBAL_WAVES
 #define PT_TREE_GLOBAL_WAVES 6 // 5 / 6 waves per SIMD: 37.4 / 35.6 ms per 256 samples of 3 000 spheres, 230.9 / 215.4 ms per frame of 100 000 (the walk waits on L2)
 #endif
 __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES : PT_TREE_LDS_WAVES) : PT_WAVES_PER_SIMD) void pt_megakernel(const KParams P) {
+    constexpr bool DET = MODE == kModeDet, DIRECT = MODE == kModeDirect;
     constexpr bool TREE_LDS = TREE && !MULTI_TILE;
     constexpr bool TABLES_LDS = !MULTI_TILE && !TREE;      // filter table, radii and materials of a one-tile scene
     __shared__ float4 s_filt[TREE ? 1 : kTile + kSub];      // (cx, cz, T, cy) filter records of the current tile
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
             rng.next2(xi_u, xi_v);
             const float u = ((float)i_col + xi_u) / (float)P.width;
             const float v = ((float)(P.height - i_row + 1u) + xi_v) / (float)P.height;
-            cast_ray(P.cam, u, v, rng, o, d);
+            cast_ray<DIRECT>(P.cam, u, v, rng, o, d);
             bounce = 0;
             need_path = false;
         }
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
                     PT_STAMP(tH0);
                     sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
                     PT_STAMP(tH1);
-                    const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                    const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
                     PT_STAMP(tH2);
                     PT_SUB_ACC(0, tH0, tH1); PT_SUB_ACC(1, tH1, tH2);
 #ifndef PT_EXPERIMENT_NO_STACK // tools/build_variant.sh timing experiment (breaks parity)
@@ -1301,8 +1305,9 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
 // One thread per path of the launch, in record order (item-major, the item's samples consecutive): the
 // camera ray (renderers/ppm_image.zig:50-51,61-63), Scene.is_hit over the pixel's list, one radiance step
 // (illumination.zig:76-90 at depth 0).
-template <bool DET, bool MULTI_TILE>
+template <int MODE, bool MULTI_TILE>
 __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
+    constexpr bool DET = MODE == kModeDet, DIRECT = MODE == kModeDirect;
     // scenes of one tile keep the sphere tables in LDS (19 KiB; the grid-stride loop reuses them): the candidate loop's
     // geometry reads were dependent global loads, and the kernel waited on memory 42 % of its wave cycles
     __shared__ float4 s_geom[MULTI_TILE ? 1 : kTile];
@@ -1339,7 +1344,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             rng.next2(xi_u, xi_v);
             const float u = ((float)i_col + xi_u) / (float)P.width;
             const float v = ((float)(P.height - i_row + 1u) + xi_v) / (float)P.height;
-            const V3 disk = random_vector_in_unit_disk(rng);
+            const V3 disk = random_vector_in_unit_disk<DIRECT>(rng);
             V3 o, d;
             cast_ray_from_disk(P.cam, u, v, disk, o, d);
             const uint32_t *L = P.lists + (size_t)po * kListStride;
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                             const uint32_t kind = kind_of((uint32_t)hit);
                             V3 p, n;
                             sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
-                            const V3 nd = scatter_pre(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                            const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
                             const uint32_t drawn = rng.drawn();
                             if (depth == 0u) {
                                 hit0 = (uint32_t)hit;
@@ -1446,7 +1451,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
     if ((threadIdx.x & 63u) == 0u) {
         if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays + w_rays2); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
         if (w_rays2) atomicAdd(&P.counters[CNT_LIST2_RAYS], w_rays2);
-        if (w_cands) atomicAdd(&P.counters[CNT_CANDS], w_cands);
+        if (w_cands) { atomicAdd(&P.counters[CNT_CANDS], w_cands); atomicAdd(&P.counters[CNT_PRIMARY_CANDS], w_cands); }
         if (w_nu) atomicAdd(&P.counters[CNT_NOT_UNIT], w_nu);
     }
 }
@@ -1614,6 +1619,15 @@ __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t 
         ArrayRng ar{r + 11, 0u, 16u};
         const V3 nd = scatter((uint32_t)r[9], r[10], v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), v3(r[6], r[7], r[8]), ar);
         w[0] = nd.x; w[1] = nd.y; w[2] = nd.z; w[3] = (float)ar.n;
+    } else if (fn == PT_FN_SAMPLE_DISK || fn == PT_FN_SAMPLE_BALL) {
+        // in: sampler, xi[16] (17)   out: p (3), n_used (4)
+        const float *r = in + (size_t)i * 17; float *w = out + (size_t)i * 4;
+        ArrayRng ar{r + 1, 0u, 16u};
+        const bool direct = r[0] != 0.0f;
+        V3 p;
+        if (fn == PT_FN_SAMPLE_DISK) p = direct ? random_vector_in_unit_disk<true>(ar) : random_vector_in_unit_disk<false>(ar);
+        else p = direct ? random_vector_in_unit_sphere<true>(ar) : random_vector_in_unit_sphere<false>(ar);
+        w[0] = p.x; w[1] = p.y; w[2] = p.z; w[3] = (float)ar.n;
     }
 }
 
@@ -1697,8 +1711,13 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
 // hipGetSymbolAddress, with that device current); host code only ever uses that resolved pointer.
 #define PT_SCRATCH_BYTES (128ull << 20)
 static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
-constexpr uint32_t kMaxTimedSegments = 64; // renders of more segments report primary_ms = 0
+constexpr uint32_t kMaxTimedSegments = 64; // renders of more segments report primary_ms = lists_ms = megakernel_ms = 0
+constexpr uint32_t kSegEvents = 4;         // per timed segment: before the lists, after them, after pt_primary, after the megakernel
+constexpr uint32_t kPrecreatedSegments = 4; // event sets made by ptgpu_create (the no-allocation entry point creates none: further segments go untimed)
 constexpr size_t kScratchCounters = 256; // bytes reserved for the CNT_N counters at the start of the scratch
+
+constexpr uint64_t kPrimaryAuto = ~0ull;          // PT_LIMIT_PRIMARY_BYTES default: half of the device memory that is free at the render, at most kPrimaryAutoMax
+constexpr uint64_t kPrimaryAutoMax = 96ull << 30;
 
 struct ptgpu_ctx {
     int device = -1;
@@ -1730,11 +1749,11 @@ struct ptgpu_ctx {
     int resident[2][2] = {{0, 0}, {0, 0}};           // [det][multi]: workgroups per CU the occupancy query reports
     int blocks_per_cu = 0; // 0: what the occupancy query reports; PTGPU_BLOCKS_PER_CU overrides (experiments)
     uint64_t partial_cap = 2ull << 30;               // PT_LIMIT_PARTIAL_BYTES
-    uint64_t primary_cap = 96ull << 30;              // PT_LIMIT_PRIMARY_BYTES (0: no primary pass)
+    uint64_t primary_cap = kPrimaryAuto;             // PT_LIMIT_PRIMARY_BYTES (0: no primary pass; kPrimaryAuto: sized per render from hipMemGetInfo)
     uint32_t primary_bounces = 2;                    // PT_LIMIT_PRIMARY_BOUNCES: 1 = camera rays only, 2 = also the rays scattered off each pixel's main sphere
     unsigned char *d_prim = nullptr; size_t prim_bytes = 0; // primary-pass records + candidate lists
     void *d_lsph = nullptr; size_t lsph_bytes = 0;          // ListSphere per sphere (pt_list_prep)
-    std::vector<hipEvent_t> evp;                     // pairs around the primary pass of each segment (grown on demand)
+    std::vector<hipEvent_t> evp;                     // kSegEvents per timed segment (kPrecreatedSegments sets from ptgpu_create, grown on demand)
     pt_stats stats;
 };
 
@@ -1796,21 +1815,26 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev2);
+    for (uint32_t i = 0; i < kSegEvents * kPrecreatedSegments && e == hipSuccess; ++i) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreate(&ev);
+        if (e == hipSuccess) ctx->evp.push_back(ev);
+    }
     // this device's address of the static scratch array (device `device` is current here)
     if (e == hipSuccess) e = hipGetSymbolAddress((void **)&ctx->d_scratch, HIP_SYMBOL(scratch));
     if (e == hipSuccess) {
         // workgroups per CU each kernel variant can keep resident (the persistent grid's size)
         int r = 0;
         // (the variants that start paths from primary-pass records have the same launch bounds and LDS)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][1] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeRejection, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeRejection, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[0][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeDet, false, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeDet, true, false>, kBlock, 0) == hipSuccess && r > 0) ctx->resident[1][1] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident[i][j] <= 0) ctx->resident[i][j] = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][1] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][1] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<false, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][0] = r;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<true, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeRejection, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeDet, true, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][1] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeRejection, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[0][0] = r;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, pt_megakernel<kModeDet, false, false, true>, kBlock, 0) == hipSuccess && r > 0) ctx->resident_tree[1][0] = r;
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) if (ctx->resident_tree[i][j] <= 0) ctx->resident_tree[i][j] = 1;
     }
     if (e != hipSuccess || !ctx->d_scratch) {
@@ -1819,6 +1843,7 @@ extern "C" int ptgpu_create(int device, ptgpu_ctx **out) {
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
         if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+        for (hipEvent_t ev : ctx->evp) (void)hipEventDestroy(ev);
         delete ctx;
         return PT_ERR_HIP;
     }
@@ -1880,7 +1905,12 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
         ctx->partial_cap = value;
         return PT_OK;
     case PT_LIMIT_PRIMARY_BYTES:
-        ctx->primary_cap = value;
+        ctx->primary_cap = value; // (~0: back to the automatic size)
+        if (ctx->d_prim && (uint64_t)ctx->prim_bytes > value) { // a lowered limit gives the memory back now, not at ptgpu_destroy
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            HIP_TRY(ctx, hipFree(ctx->d_prim));
+            ctx->d_prim = nullptr; ctx->prim_bytes = 0;
+        }
         return PT_OK;
     case PT_LIMIT_PRIMARY_BOUNCES:
         if (value < 1 || value > 2) return PT_ERR_BAD_ARG;
@@ -1892,6 +1922,23 @@ extern "C" int ptgpu_set_limit(ptgpu_ctx *ctx, int which, uint64_t value) {
         return PT_OK;
     default: return PT_ERR_BAD_ARG;
     }
+}
+
+// Gives back every work buffer the context has grown (records and lists of the primary pass, chunk partials, hit-id stack,
+// staging images); scene tables stay.  The next render allocates again what it needs.
+extern "C" int ptgpu_trim(ptgpu_ctx *ctx) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void **ptrs[] = {(void **)&ctx->d_prim, (void **)&ctx->d_part, (void **)&ctx->d_stack, (void **)&ctx->d_tmp, (void **)&ctx->d_rec, &ctx->d_lsph};
+    size_t *sizes[] = {&ctx->prim_bytes, &ctx->part_bytes, &ctx->stack_bytes, &ctx->tmp_bytes, &ctx->rec_bytes, &ctx->lsph_bytes};
+    for (int i = 0; i < 6; ++i) {
+        if (*ptrs[i]) HIP_TRY(ctx, hipFree(*ptrs[i]));
+        *ptrs[i] = nullptr; *sizes[i] = 0;
+    }
+    return PT_OK;
+}
+extern "C" uint64_t ptgpu_work_bytes(const ptgpu_ctx *ctx) {
+    return ctx ? (uint64_t)ctx->prim_bytes + ctx->part_bytes + ctx->stack_bytes + ctx->tmp_bytes + ctx->rec_bytes + ctx->lsph_bytes : 0u;
 }
 
 extern "C" uint64_t ptgpu_noalloc_scratch_bytes(void) { return PT_SCRATCH_BYTES; }
@@ -2187,7 +2234,7 @@ static int check_cfg(const ptgpu_ctx *ctx, const pt_config *cfg, uint32_t *s0, u
     const uint64_t np = (uint64_t)cfg->width * cfg->height;
     if (np > 0x7fffffffull / 3) return PT_ERR_BAD_ARG;
     if (cfg->idx_start > cfg->idx_stop || cfg->idx_stop > np) return PT_ERR_BAD_ARG;
-    if (cfg->mode > 1 || cfg->illumination > PT_ILLUM_ALBEDO) return PT_ERR_BAD_ARG;
+    if (cfg->mode > 1 || cfg->illumination > PT_ILLUM_ALBEDO || cfg->sampler > PT_SAMPLER_DIRECT) return PT_ERR_BAD_ARG;
     if (cfg->tile_pixels != 0 &&
         (cfg->tile_count == 0 || cfg->tile_index >= cfg->tile_count || cfg->idx_start % cfg->tile_pixels != 0))
         return PT_ERR_BAD_ARG;
@@ -2236,29 +2283,35 @@ struct Workspace {
     float *part; size_t part_bytes;
 };
 
-template <bool PRIMARY>
-static void launch_megakernel_p(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+template <int MODE, bool PRIMARY>
+static void launch_megakernel_mp(bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
     if (P.tnodes) {
-        if (det) {
-            if (multi) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-            else hipLaunchKernelGGL((pt_megakernel<true, false, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        } else {
-            if (multi) hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-            else hipLaunchKernelGGL((pt_megakernel<false, false, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
-        }
+        if (multi) hipLaunchKernelGGL((pt_megakernel<MODE, true, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL((pt_megakernel<MODE, false, PRIMARY, true>), dim3(grid), dim3(kBlock), 0, stream, P);
         return;
     }
-    if (det) {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<true, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<true, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
-    } else {
-        if (multi) hipLaunchKernelGGL((pt_megakernel<false, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
-        else hipLaunchKernelGGL((pt_megakernel<false, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
-    }
+    if (multi) hipLaunchKernelGGL((pt_megakernel<MODE, true, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
+    else hipLaunchKernelGGL((pt_megakernel<MODE, false, PRIMARY>), dim3(grid), dim3(kBlock), 0, stream, P);
 }
-static void launch_megakernel(bool det, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
-    if (P.primary) launch_megakernel_p<true>(det, multi, grid, stream, P);
-    else launch_megakernel_p<false>(det, multi, grid, stream, P);
+template <int MODE>
+static void launch_megakernel_m(bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+    if (P.primary) launch_megakernel_mp<MODE, true>(multi, grid, stream, P);
+    else launch_megakernel_mp<MODE, false>(multi, grid, stream, P);
+}
+static void launch_megakernel(int mode, bool multi, uint32_t grid, hipStream_t stream, const KParams &P) {
+    if (mode == kModeDet) launch_megakernel_m<kModeDet>(multi, grid, stream, P);
+    else if (mode == kModeDirect) launch_megakernel_m<kModeDirect>(multi, grid, stream, P);
+    else launch_megakernel_m<kModeRejection>(multi, grid, stream, P);
+}
+template <int MODE>
+static void launch_primary_m(bool multi, uint32_t pgrid, hipStream_t stream, const KParams &P, uint32_t nrec) {
+    if (multi) hipLaunchKernelGGL((pt_primary<MODE, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+    else hipLaunchKernelGGL((pt_primary<MODE, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+}
+static void launch_primary(int mode, bool multi, uint32_t pgrid, hipStream_t stream, const KParams &P, uint32_t nrec) {
+    if (mode == kModeDet) launch_primary_m<kModeDet>(multi, pgrid, stream, P, nrec);
+    else if (mode == kModeDirect) launch_primary_m<kModeDirect>(multi, pgrid, stream, P, nrec);
+    else launch_primary_m<kModeRejection>(multi, pgrid, stream, P, nrec);
 }
 
 // The render behind both ptgpu_render_sum_device (workspace from hipMalloc, grown on demand) and
@@ -2287,6 +2340,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     const bool tree = ctx->tree_nodes != 0u;
     const bool multi = ctx->n_pad > (uint32_t)kTile; // with a tree: walked in global memory (else staged in LDS)
     const bool det = cfg->mode == 1;
+    const int mode = det ? kModeDet : (cfg->sampler == PT_SAMPLER_DIRECT ? kModeDirect : kModeRejection); // (the deterministic mode has no sampler: every draw is 0.5)
     // persistent grid: as many workgroups per CU as the kernel variant can keep resident
     const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (tree ? ctx->resident_tree : ctx->resident)[det ? 1 : 0][multi ? 1 : 0];
     const uint32_t grid = (uint32_t)(ctx->compute_units * bpc);
@@ -2318,12 +2372,19 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     const uint64_t prim_per_slot = (uint64_t)nchunks * chunk * 32u + (uint64_t)kListStride * sizeof(uint32_t) + (uint64_t)nchunks * sizeof(uint32_t);
     // the lists hold rays that leave the lens forwards; the no-allocation entry point keeps the camera rays in the megakernel
     uint64_t prim_cap = (noalloc || cfg->t_min < 0.0f || ctx->nspheres > kHitMask) ? 0u : ctx->primary_cap;
+    if (prim_cap == kPrimaryAuto) {
+        // Sized from what the device has free NOW (plus what this context already holds for the pass): half of it, so that a
+        // host sharing the GPU with other allocators keeps room; the buffer is then allocated at the size the render needs.
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        prim_cap = std::min<uint64_t>(kPrimaryAutoMax, ((uint64_t)free_b + (uint64_t)ctx->prim_bytes) / 2u);
+    }
     const uint64_t part_fit = fit_slots(part_avail, part_per_slot);
     if (part_fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
     bool primary;
     uint32_t seg;
     size_t prim_rec_bytes = 0;
-    for (;;) { // sized once, unless the device cannot give the primary pass its buffer: then with half of it, ..., then without the pass
+    for (;;) { // sized once; should the allocation still fail (another process took the memory since the query): with half of it, ..., then without the pass
         primary = prim_cap > 1024u && fit_slots(prim_cap - 1024u, prim_per_slot) >= 64;
         uint64_t fit = part_fit;
         if (primary) fit = std::min(fit, fit_slots(prim_cap - 1024u, prim_per_slot));
@@ -2390,26 +2451,30 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
 
     HIP_TRY(ctx, hipMemsetAsync(ws.counters, 0, CNT_N * sizeof(unsigned long long), stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    if (primary) {
-        hipLaunchKernelGGL(pt_list_prep, dim3((ctx->nspheres + 255u) / 256u), dim3(256), 0, stream, LC, (const float4 *)ctx->d_geom, ctx->nspheres,
-                           (ListSphere *)ctx->d_lsph);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    uint32_t nseg = 0;
+    uint32_t nseg = 0, n_timed = 0;
     for (uint32_t slot0 = 0; slot0 < npix; slot0 += seg, ++nseg) {
         P.slot0 = slot0;
         P.npix = std::min(seg, npix - slot0);
         P.div_npix = make_fastdiv(P.npix);
         if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
+        bool timed = nseg < kMaxTimedSegments;
+        if (timed && ctx->evp.size() < (size_t)kSegEvents * (nseg + 1u)) {
+            if (noalloc) timed = false; // no event is created on this path
+            else while (ctx->evp.size() < (size_t)kSegEvents * (nseg + 1u)) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(ctx, hipEventCreate(&e));
+                ctx->evp.push_back(e);
+            }
+        }
+        if (timed) n_timed++;
+        hipEvent_t *evs = timed ? &ctx->evp[(size_t)kSegEvents * nseg] : nullptr;
+        if (timed) HIP_TRY(ctx, hipEventRecord(evs[0], stream));
+        if (!primary && timed) { HIP_TRY(ctx, hipEventRecord(evs[1], stream)); HIP_TRY(ctx, hipEventRecord(evs[2], stream)); }
         if (primary) {
-            const bool timed = nseg < kMaxTimedSegments;
-            if (timed) {
-                while (ctx->evp.size() < 2u * (nseg + 1u)) {
-                    hipEvent_t e = nullptr;
-                    HIP_TRY(ctx, hipEventCreate(&e));
-                    ctx->evp.push_back(e);
-                }
-                HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg], stream));
+            if (nseg == 0) { // what the lists need of each sphere, once per render
+                hipLaunchKernelGGL(pt_list_prep, dim3((ctx->nspheres + 255u) / 256u), dim3(256), 0, stream, LC, (const float4 *)ctx->d_geom, ctx->nspheres,
+                                   (ListSphere *)ctx->d_lsph);
+                HIP_TRY(ctx, hipGetLastError());
             }
             const uint32_t second = (ctx->primary_bounces >= 2 && cfg->illumination == PT_ILLUM_RADIANCE && cfg->rebounds >= 2u) ? 1u : 0u;
             if (tree && multi) // (a one-tile scene's lists come from the loop over its spheres either way: 1.5 ms per launch, ascending order)
@@ -2423,20 +2488,16 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
                                    ctx->nspheres, (const uint32_t *)ctx->d_kind, (const float4 *)ctx->d_mat, cfg->t_min, second, d_lists,
                                    (const TreeNode *)nullptr, (const uint32_t *)nullptr, 0u);
             HIP_TRY(ctx, hipGetLastError());
+            if (timed) HIP_TRY(ctx, hipEventRecord(evs[1], stream));
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
             const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);
-            if (det) {
-                if (multi) hipLaunchKernelGGL((pt_primary<true, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
-                else hipLaunchKernelGGL((pt_primary<true, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
-            } else {
-                if (multi) hipLaunchKernelGGL((pt_primary<false, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
-                else hipLaunchKernelGGL((pt_primary<false, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
-            }
+            launch_primary(mode, multi, pgrid, stream, P, nrec);
             HIP_TRY(ctx, hipGetLastError());
-            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->evp[2u * nseg + 1u], stream));
+            if (timed) HIP_TRY(ctx, hipEventRecord(evs[2], stream));
         }
-        launch_megakernel(det, multi, grid, stream, P);
+        launch_megakernel(mode, multi, grid, stream, P);
         HIP_TRY(ctx, hipGetLastError());
+        if (timed) HIP_TRY(ctx, hipEventRecord(evs[3], stream));
         if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // one segment: ev0..ev1 is the tracing kernels alone
         if (nchunks > 1) {
             const uint32_t n3 = P.npix * 3u;
@@ -2460,12 +2521,16 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     ctx->stats.primary_rays = h[CNT_PRIMARY_RAYS];
     ctx->stats.list2_rays = h[CNT_LIST2_RAYS];
     ctx->stats.box_tests = h[CNT_BOX_TESTS];
-    ctx->stats.primary_ms = 0.0;
-    if (primary && nseg <= kMaxTimedSegments) {
+    ctx->stats.primary_candidates = h[CNT_PRIMARY_CANDS];
+    ctx->stats.primary_ms = ctx->stats.lists_ms = ctx->stats.megakernel_ms = 0.0;
+    if (n_timed == nseg) { // every segment carried its events
         for (uint32_t i = 0; i < nseg; ++i) {
-            float msp = 0.f;
-            HIP_TRY(ctx, hipEventElapsedTime(&msp, ctx->evp[2u * i], ctx->evp[2u * i + 1u]));
-            ctx->stats.primary_ms += msp;
+            const hipEvent_t *evs = &ctx->evp[(size_t)kSegEvents * i];
+            float ms_l = 0.f, ms_p = 0.f, ms_m = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms_l, evs[0], evs[1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms_p, evs[0], evs[2]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms_m, evs[2], evs[3]));
+            ctx->stats.lists_ms += ms_l; ctx->stats.primary_ms += ms_p; ctx->stats.megakernel_ms += ms_m;
         }
     }
     ctx->stats.not_unit = h[CNT_NOT_UNIT];
@@ -2498,10 +2563,12 @@ extern "C" int ptgpu_render_sum_device_noalloc(ptgpu_ctx *ctx, const pt_config *
 
 extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_sum) {
     if (!ctx || !cfg || !h_rgb_sum) return PT_ERR_BAD_ARG;
-    const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
-    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    uint32_t s0_, s1_, chunk_;
+    int rc = check_cfg(ctx, cfg, &s0_, &s1_, &chunk_); // before anything is allocated from cfg's sizes
     if (rc != PT_OK) return rc;
-    if (cfg->idx_start > cfg->idx_stop || (uint64_t)cfg->idx_stop > (uint64_t)cfg->width * cfg->height) return PT_ERR_BAD_ARG;
+    const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
+    rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    if (rc != PT_OK) return rc;
     const size_t off = (size_t)cfg->idx_start * 3u, cnt = (size_t)(cfg->idx_stop - cfg->idx_start) * 3u;
     // tile split: other owners' pixels inside the range must come back untouched
     if (cfg->tile_pixels != 0 && cnt) HIP_TRY(ctx, hipMemcpy(ctx->d_tmp + off, h_rgb_sum + off, cnt * sizeof(float), hipMemcpyHostToDevice));
@@ -2514,8 +2581,11 @@ extern "C" int ptgpu_render_sum_host(ptgpu_ctx *ctx, const pt_config *cfg, float
 extern "C" int ptgpu_render_mean_host(ptgpu_ctx *ctx, const pt_config *cfg, float *h_rgb_mean) {
     if (!ctx || !cfg || !h_rgb_mean) return PT_ERR_BAD_ARG;
     if (cfg->tile_pixels != 0) return PT_ERR_UNSUPPORTED; // resolve whole ranges only: combine the owners' sums first
+    uint32_t s0_, s1_, chunk_;
+    int rc = check_cfg(ctx, cfg, &s0_, &s1_, &chunk_); // before anything is allocated from cfg's sizes
+    if (rc != PT_OK) return rc;
     const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
-    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
     if (rc != PT_OK) return rc;
     rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
     if (rc != PT_OK && rc != PT_ERR_DIRECTION_NOT_UNIT) return rc;
@@ -2558,11 +2628,13 @@ extern "C" int ptgpu_render_ppm(ptgpu_ctx *ctx, const pt_config *cfg, uint8_t *s
                                 uint32_t px_size) {
     if (!ctx || !cfg || !slice) return PT_ERR_BAD_ARG;
     if (cfg->max_px_value != 255u || px_size != 12u || cfg->tile_pixels != 0) return PT_ERR_UNSUPPORTED;
-    if (cfg->idx_start > cfg->idx_stop) return PT_ERR_BAD_ARG;
+    uint32_t s0_, s1_, chunk_;
+    int rc = check_cfg(ctx, cfg, &s0_, &s1_, &chunk_); // before anything is allocated from cfg's sizes
+    if (rc != PT_OK) return rc;
     const uint32_t npix = cfg->idx_stop - cfg->idx_start;
     if ((size_t)header_size + (size_t)cfg->idx_stop * px_size > slice_len) return PT_ERR_NO_SPACE;
     const size_t bytes = (size_t)cfg->width * cfg->height * 3u * sizeof(float);
-    int rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
+    rc = ensure(ctx, (void **)&ctx->d_tmp, &ctx->tmp_bytes, bytes);
     if (rc != PT_OK) return rc;
     rc = ptgpu_render_sum_device(ctx, cfg, ctx->d_tmp, nullptr);
     if (rc != PT_OK) return rc; // DirectionIsNotUnitVector aborts render() (renderers/ppm_image.zig:66 `try`)
@@ -2594,6 +2666,7 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
     case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 3; break;
     case PT_FN_SCENE_HIT_TREE: in_stride = 6; out_stride = 8; break;
+    case PT_FN_SAMPLE_DISK: case PT_FN_SAMPLE_BALL: in_stride = 17; out_stride = 4; break;
     default: return PT_ERR_UNSUPPORTED;
     }
     if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
@@ -2633,7 +2706,7 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
             else
                 hipLaunchKernelGGL((pt_debug_scene_hit_filtered<false>), dim3(blocks), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
                                    (const float4 *)ctx->d_filt, (const float *)ctx->d_ycy, (const float4 *)ctx->d_geom, ctx->nspheres, t_min, t_max);
-        } else if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER)
+        } else if (fn == PT_FN_CAST_RAY || fn == PT_FN_SCATTER || fn == PT_FN_SAMPLE_DISK || fn == PT_FN_SAMPLE_BALL)
             hipLaunchKernelGGL(pt_debug_eval_rng, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam);
         else
             hipLaunchKernelGGL(pt_debug_eval, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, fn, (const float *)d_in, d_out, n, cam,

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -32,8 +33,12 @@ struct Rccl {
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
-    bool load() {
-        if (handle) return true;
+    std::once_flag once;
+    bool load() { // (two threads may create their first multi-GPU handle at the same time)
+        std::call_once(once, [this] { load_once(); });
+        return handle != nullptr;
+    }
+    bool load_once() {
         void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return false;
@@ -59,6 +64,7 @@ struct ptgpu_multi {
     std::vector<float *> frame;      // per-device W*H*3 sums (device 0's receives the reduce)
     std::vector<size_t> frame_bytes;
     std::vector<ncclComm_t> comm;    // empty: no communicator (one GPU, RCCL not forced)
+    bool host_sum = false;           // tests only (PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES=1 and a device listed twice): frames added on the host
     uint8_t *d_rec = nullptr; size_t rec_bytes = 0; // device 0: records of ptgpu_multi_render_ppm
     std::vector<pt_stats> stats;
     double reduce_ms = 0.0;
@@ -118,9 +124,16 @@ extern "C" int ptgpu_multi_create(const int *devices, int num_gpus, ptgpu_multi 
     if (!m) return PT_ERR_OOM;
     m->n = num_gpus;
     for (int g = 0; g < num_gpus; ++g) m->devices.push_back(devices ? devices[g] : g);
+    // One context per GPU.  Tests only: PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES=1 lets a device appear more than once, so that the
+    // whole N > 1 plan — threads, zeroed frames, shares, the sum on GPU 0 — runs on a one-GPU box; RCCL cannot put two ranks
+    // on one device, so the frames are then added on the host, in GPU order (x + 0 = x under the tile split).
+    const char *dup_ok = getenv("PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES");
     for (int g = 0; g < num_gpus; ++g)
         for (int h = 0; h < g; ++h)
-            if (m->devices[g] == m->devices[h]) { delete m; return PT_ERR_BAD_ARG; } // one context per GPU
+            if (m->devices[g] == m->devices[h]) {
+                if (!(dup_ok && atoi(dup_ok) > 0)) { delete m; return PT_ERR_BAD_ARG; }
+                m->host_sum = true;
+            }
     m->stats.assign(num_gpus, pt_stats());
     m->frame.assign(num_gpus, nullptr);
     m->frame_bytes.assign(num_gpus, 0);
@@ -137,7 +150,7 @@ extern "C" int ptgpu_multi_create(const int *devices, int num_gpus, ptgpu_multi 
         m->stream.push_back(s);
     }
     const char *force = getenv("PTGPU_MULTI_FORCE_RCCL"); // tests: run the collective on a single GPU too
-    if (num_gpus > 1 || (force && atoi(force) > 0)) {
+    if (!m->host_sum && (num_gpus > 1 || (force && atoi(force) > 0))) {
         if (!g_rccl.load()) { ptgpu_multi_destroy(m); return PT_ERR_RCCL; }
         m->comm.assign(num_gpus, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), num_gpus, m->devices.data());
@@ -205,8 +218,15 @@ static int render_sum_on_devices(ptgpu_multi *m, const pt_config *cfg, int split
     };
     if (m->n == 1) work(0);
     else {
+        // (nothing thrown here may cross the extern "C" boundary: a thread that cannot be started leaves its share to this one)
         std::vector<std::thread> threads;
-        for (int g = 0; g < m->n; ++g) threads.emplace_back(work, g); // main.zig:155-161
+        std::vector<int> started(m->n, 0);
+        try { threads.reserve(m->n); } catch (...) { return PT_ERR_OOM; }
+        for (int g = 0; g < m->n; ++g) {
+            try { threads.emplace_back(work, g); started[g] = 1; } // main.zig:155-161
+            catch (...) { started[g] = 0; }
+        }
+        for (int g = 0; g < m->n; ++g) if (!started[g]) work(g);
         for (auto &t : threads) t.join();                            // main.zig:163-165
     }
     int not_unit = PT_OK;
@@ -215,6 +235,17 @@ static int render_sum_on_devices(ptgpu_multi *m, const pt_config *cfg, int split
         else if (rcs[g] != PT_OK) return rcs[g];
     }
     m->reduce_ms = 0.0;
+    if (m->host_sum && m->n > 1 && cnt) { // tests only: see ptgpu_multi_create
+        std::vector<float> acc, part;
+        try { acc.resize(cnt); part.resize(cnt); } catch (...) { return PT_ERR_OOM; }
+        for (int g = 0; g < m->n; ++g) {
+            if (hipSetDevice(m->devices[g]) != hipSuccess) return PT_ERR_HIP;
+            if (hipMemcpy(g == 0 ? acc.data() : part.data(), m->frame[g] + off, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return PT_ERR_HIP;
+            if (g > 0) for (size_t i = 0; i < cnt; ++i) acc[i] = acc[i] + part[i];
+        }
+        if (hipSetDevice(m->devices[0]) != hipSuccess) return PT_ERR_HIP;
+        if (hipMemcpy(m->frame[0] + off, acc.data(), cnt * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PT_ERR_HIP;
+    }
     if (!m->comm.empty() && cnt) {
         // the path's one exchange step: fp32 sums -> GPU 0 (in place on the root)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -288,8 +319,10 @@ extern "C" int ptgpu_multi_get_stats(const ptgpu_multi *m, int gpu, pt_stats *ou
     for (int g = 0; g < m->n; ++g) { // totals; times = the slowest GPU (they run side by side)
         const pt_stats &s = m->stats[g];
         t.paths += s.paths; t.rays += s.rays; t.sphere_tests += s.sphere_tests; t.candidates += s.candidates;
-        t.not_unit += s.not_unit; t.wave_steps += s.wave_steps; t.flush_iters += s.flush_iters; t.segments += s.segments; t.primary_rays += s.primary_rays; t.list2_rays += s.list2_rays; t.box_tests += s.box_tests;
+        t.not_unit += s.not_unit; t.wave_steps += s.wave_steps; t.flush_iters += s.flush_iters; t.segments += s.segments; t.primary_rays += s.primary_rays; t.list2_rays += s.list2_rays; t.box_tests += s.box_tests; t.primary_candidates += s.primary_candidates;
         if (s.primary_ms > t.primary_ms) t.primary_ms = s.primary_ms;
+        if (s.lists_ms > t.lists_ms) t.lists_ms = s.lists_ms;
+        if (s.megakernel_ms > t.megakernel_ms) t.megakernel_ms = s.megakernel_ms;
         if (s.kernel_ms > t.kernel_ms) t.kernel_ms = s.kernel_ms;
         if (s.total_ms > t.total_ms) t.total_ms = s.total_ms;
     }

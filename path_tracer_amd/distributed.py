@@ -62,11 +62,13 @@ def render_sum_distributed(render_into, img, rt, seed, split="samples", chunk=0,
     return frame
 
 
-def gpu_render_into(gpu):
-    """render_into for a GpuContext: enqueue on torch's current stream, device memory only."""
+def gpu_render_into(gpu, sampler=0):
+    """render_into for a GpuContext: enqueue on torch's current stream, device memory only.
+    sampler: pt_config.sampler of every render (PT_SAMPLER_REJECTION, the reference's loops, unless asked otherwise)."""
 
     def fn(cfg, frame):
         assert frame.is_cuda and frame.dtype == torch.float32 and frame.is_contiguous()
+        cfg.sampler = int(sampler)
         gpu.render_sum_device(cfg, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     return fn

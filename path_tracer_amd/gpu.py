@@ -87,6 +87,13 @@ class GpuContext:
     def set_limit(self, which, value):
         check(self._L.ptgpu_set_limit(self._h, int(which), int(value)), "ptgpu_set_limit")
 
+    def trim(self):
+        """ptgpu_trim: free every work buffer the renders have grown (the scene stays)."""
+        check(self._L.ptgpu_trim(self._h), "ptgpu_trim")
+
+    def work_bytes(self):
+        return int(self._L.ptgpu_work_bytes(self._h))
+
     def resolve_device(self, cfg, d_sum, d_records=0, d_rgb8=0, stream=0):
         cfg = self.as_config(cfg)
         check(self._L.ptgpu_resolve_device(self._h, C.byref(cfg), C.c_void_p(int(d_sum)), C.c_void_p(int(d_records)),

@@ -199,7 +199,7 @@ def filepath(num_scene, cfg, img, seed):
 
 
 def make_pt_config(img, rt, seed=0, istart=0, istop=None, deterministic=False, sample_start=0, sample_stop=0, chunk=0,
-                   tile_pixels=0, tile_count=1, tile_index=0, illumination=0):
+                   tile_pixels=0, tile_count=1, tile_index=0, illumination=0, sampler=0):
     c = pt_config()
     c.width, c.height = img.width, img.height
     c.subpixels, c.rays_per_subsample, c.rebounds = rt.subpixels, rt.rays_per_subsample, rt.rebounds
@@ -214,6 +214,7 @@ def make_pt_config(img, rt, seed=0, istart=0, istop=None, deterministic=False, s
     c.max_px_value = img.max_px_value
     c.tile_pixels, c.tile_count, c.tile_index = int(tile_pixels), int(tile_count), int(tile_index)
     c.illumination = int(illumination)
+    c.sampler = int(sampler)   # _lib.PT_SAMPLER_*
     return c
 
 

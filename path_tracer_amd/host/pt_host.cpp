@@ -275,6 +275,7 @@ static int to_pt_config(const Config &cfg, pt_config *c) {
     c->idx_start = (uint32_t)cfg.istart; c->idx_stop = (uint32_t)cfg.istop;
     c->chunk = cfg.chunk;
     c->illumination = cfg.illumination;
+    c->sampler = cfg.sampler;
     c->max_px_value = (uint32_t)img.max_px_value;
     c->tile_count = 1;
     return PT_OK;

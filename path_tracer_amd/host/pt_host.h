@@ -135,6 +135,7 @@ struct Config {
     bool deterministic = false;
     uint32_t chunk = 0; // samples per GPU work item (0: one sequential sum per pixel, as the reference)
     uint32_t illumination = PT_ILLUM_RADIANCE; // renderers/ppm_image.zig:64-66: radiance | colorNormal | colorAlbedo
+    uint32_t sampler = PT_SAMPLER_REJECTION;   // camera.zig:113-120 / material.zig:27-34 as the reference loops them, or PT_SAMPLER_DIRECT (not in the reference)
 };
 
 // render(), renderers/ppm_image.zig:30-87: traces pixels [istart, istop) and writes

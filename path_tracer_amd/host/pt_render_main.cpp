@@ -15,12 +15,12 @@ using namespace pt;
 
 static void usage() {
     fprintf(stderr, "usage: pt_render [--scene 18|19|20|21] [--width W] [--spp N] [--depth D] [--seed S] [--prng xoroshiro128|xoshiro256]\n"
-                    "                 [--gpus N [--split tiles|samples]] [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--out FILE]\n");
+                    "                 [--gpus N [--split tiles|samples]] [--device G] [--deterministic] [--chunk C] [--aov radiance|normal|albedo] [--sampler rejection|direct] [--out FILE]\n");
 }
 
 int main(int argc, char **argv) {
     int num_scene = 18, device = 0, gpus = 0, split = PT_SPLIT_TILES; // --gpus: the node's GPUs instead of main.zig's threads               // prompt defaults: main.zig:50,58,63,66
-    unsigned width = 256, spp = 8, depth = 6, chunk = 0, illumination = PT_ILLUM_RADIANCE;
+    unsigned width = 256, spp = 8, depth = 6, chunk = 0, illumination = PT_ILLUM_RADIANCE, sampler = PT_SAMPLER_REJECTION;
     unsigned long long seed = 42;
     bool deterministic = false;
     Prng prng_kind = Prng::Default;
@@ -49,6 +49,12 @@ int main(int argc, char **argv) {
             else if (!strcmp(a, "xoshiro256")) prng_kind = Prng::Xoshiro256;
             else { usage(); return 2; }
         }
+        else if (!strcmp(argv[i], "--sampler")) { // the reference's rejection loops, or their direct equivalents (include/ptgpu.h)
+            const char *a = need("--sampler");
+            if (!strcmp(a, "rejection")) sampler = PT_SAMPLER_REJECTION;
+            else if (!strcmp(a, "direct")) sampler = PT_SAMPLER_DIRECT;
+            else { usage(); return 2; }
+        }
         else if (!strcmp(argv[i], "--aov")) { // the reference's commented-out colour functions (renderers/ppm_image.zig:64-65)
             const char *a = need("--aov");
             if (!strcmp(a, "normal")) illumination = PT_ILLUM_NORMAL;
@@ -75,6 +81,7 @@ int main(int argc, char **argv) {
     rcfg.deterministic = deterministic;
     rcfg.chunk = chunk;
     rcfg.illumination = illumination;
+    rcfg.sampler = sampler;
     pt_stats st;
     double reduce_ms = 0.0;
     if (gpus > 0) { // main.zig:142-165: "use the multi-threaded version" -> the GPUs of the node

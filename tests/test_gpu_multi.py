@@ -46,8 +46,52 @@ def test_multi_one_gpu_matches_single_gpu(gpu, force_rccl, monkeypatch):
             assert m.reduce_ms() > 0.0
 
 
-def test_multi_rejects_bad_devices():
+@pytest.mark.parametrize("n", [2, 3])
+def test_multi_threaded_plan_with_n_ranks_on_one_gpu(gpu, n, monkeypatch):
+    """N > 1 on the one-GPU box: PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES=1 lets device 0 stand in for every rank, so the
+    concurrent worker threads, one context / stream / zeroed frame per rank, the shares of ptgpu_multi_plan and the sum on
+    rank 0 all run (the sum on the host instead of ncclReduce: RCCL cannot put two ranks on one device).  Tile split:
+    the one-GPU frame bit for bit.  Sample split: the ranks' partial frames added in rank order."""
+    from path_tracer_amd import host
+    from path_tracer_amd.gpu import MultiGpu, multi_plan
+    monkeypatch.setenv("PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES", "1")
+    scene = host.Scene().setupScene(456, 21)
+    cam = host.Camera.preset(21)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(cam.pod)
+    img = host.Image(192)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=4, rebounds=50)
+    with MultiGpu(n, devices=[0] * n) as m:
+        assert m.num_gpus == n and not m.uses_rccl
+        m.set_scene(scene.spheres)
+        m.set_camera(cam.pod)
+        for kw in (dict(chunk=4), dict(chunk=2, istart=256 * 3, istop=192 * 90 + 11)):
+            cfg = host.make_pt_config(img, rt, seed=7, **kw)
+            want = gpu.render_sum(cfg)
+            one = gpu.stats()
+            got = m.render_sum(cfg, "tiles")
+            np.testing.assert_array_equal(got, want)
+            st = m.stats()
+            assert (st.paths, st.rays) == (one.paths, one.rays)
+            assert sum(m.stats(g).paths for g in range(n)) == st.paths and all(m.stats(g).paths > 0 for g in range(n))
+            got = m.render_sum(cfg, "samples")
+            acc = None
+            for g in range(n):
+                share = multi_plan(cfg, "samples", n, g)
+                part = gpu.render_sum(share)
+                acc = part if acc is None else acc + part
+            np.testing.assert_array_equal(got, acc)
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+        cfg = host.make_pt_config(img, rt, seed=7, chunk=4)
+        a, b = np.zeros(img.size, dtype=np.uint8), np.zeros(img.size, dtype=np.uint8)
+        gpu.render_ppm(cfg, a, img.header_size, img.px_size)
+        m.render_ppm(cfg, "tiles", b, img.header_size, img.px_size)
+        np.testing.assert_array_equal(a, b)
+
+
+def test_multi_rejects_bad_devices(monkeypatch):
     from path_tracer_amd import _lib
+    monkeypatch.delenv("PTGPU_MULTI_ALLOW_DUPLICATE_DEVICES", raising=False)
     from path_tracer_amd._lib import PtGpuError
     from path_tracer_amd.gpu import MultiGpu
     with pytest.raises(PtGpuError) as e:

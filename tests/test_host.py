@@ -20,7 +20,7 @@ def test_libptgpu_exports_every_declared_symbol():
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ptgpu_abi_version() == 2
+    assert L.ptgpu_abi_version() == 3
     assert _lib.strerror(_lib.PT_ERR_DIRECTION_NOT_UNIT) == "DirectionIsNotUnitVector"
     assert _lib.strerror(_lib.PT_ERR_SCENE_NOT_AVAILABLE) == "SceneNotAvailable"
 
@@ -29,9 +29,9 @@ def test_pod_layouts_match_header():
     from path_tracer_amd import _lib
     assert _lib.SPHERE_DTYPE.itemsize == 36
     assert C.sizeof(_lib.pt_camera) == 76
-    assert C.sizeof(_lib.pt_config) == 104
+    assert C.sizeof(_lib.pt_config) == 112 and _lib.pt_config.sampler.offset == 104
     assert _lib.pt_config.seed.offset == 24 and _lib.pt_config.tile_pixels.offset == 88
-    assert C.sizeof(_lib.pt_stats) == 112 and _lib.pt_stats.segments.offset == 72 and _lib.pt_stats.primary_ms.offset == 96 and _lib.pt_stats.box_tests.offset == 104
+    assert C.sizeof(_lib.pt_stats) == 136 and _lib.pt_stats.lists_ms.offset == 112 and _lib.pt_stats.primary_candidates.offset == 128 and _lib.pt_stats.segments.offset == 72 and _lib.pt_stats.primary_ms.offset == 96 and _lib.pt_stats.box_tests.offset == 104
 
 
 def test_no_gpu_means_error_not_fallback():

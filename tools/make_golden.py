@@ -161,10 +161,42 @@ def per_function(n=400, seed=2024):
     np.savez_compressed(os.path.join(OUT, "per_function.npz"), **out)
 
 
+def sampler_direct(n=600, seed=77):
+    """ORC_SAMPLER_DIRECT (not in the reference: the opt-in samplers without rejection loops): per-function vectors of both
+    samplers on the same draws, and stochastic frames in direct mode.  A file of its own: the reference-faithful fixtures
+    above are not regenerated for it."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    xi = (rng.integers(0, 1 << 23, size=(n, 16)).astype(np.float32) / np.float32(1 << 23))   # the values Random.float(f32) can take
+    xi[0, :3] = 0.0
+    xi[1, :3] = np.float32(1.0) - np.float32(2.0 ** -23)
+    xi[2, :3] = 0.5
+    xi[3, :3] = (0.0, 0.25, 1.0 - 2.0 ** -23)
+    for which in ("disk", "ball"):
+        for name, smp in (("rejection", o.SAMPLER_REJECTION), ("direct", o.SAMPLER_DIRECT)):
+            inp = np.concatenate([np.full((n, 1), smp, np.float32), xi], axis=1)
+            out["sample_%s_%s_in" % (which, name)] = inp
+            out["sample_%s_%s_out" % (which, name)] = o.sample_batch(which, smp, xi)
+    for n_scene, width in ((18, 32), (21, 64)):
+        sp, _ = o.setup_scene(n_scene, 456)
+        cam = o.camera_preset(n_scene)
+        img = o.image_new(width)
+        cfg = o.make_config(img, subpixels=4, rays_per_subsample=2, rebounds=50, mode=0, seed=456, sampler=o.SAMPLER_DIRECT)
+        rc, s, st = o.render_sum(sp, cam, cfg, 4)
+        assert rc == 0
+        out["direct_scene%d_w%d_d50_seed456" % (n_scene, width)] = s
+        out["direct_scene%d_w%d_d50_seed456_rays" % (n_scene, width)] = np.array([st.paths, st.rays], dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, "sampler_direct.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     o.build()
-    images()
-    per_function()
+    if "--only-direct" in sys.argv:
+        sampler_direct()
+    else:
+        images()
+        per_function()
+        sampler_direct()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

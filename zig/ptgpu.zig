@@ -64,6 +64,8 @@ pub const PtConfig = extern struct {
     tile_count: u32,
     tile_index: u32,
     illumination: u32, // 0 radiance, 1 colorNormal, 2 colorAlbedo (illumination.zig)
+    sampler: u32, // 0 the reference's rejection loops (camera.zig:113-120, material.zig:27-34), 1 the direct equivalents (not in the reference)
+    reserved_: u32, // 0
 };
 
 pub const PtCtx = opaque {};
@@ -188,6 +190,8 @@ fn toPtConfig(cfg: RendererConfig, seed: u64) PtConfig {
         .tile_count = 1,
         .tile_index = 0,
         .illumination = 0,
+        .sampler = 0,
+        .reserved_ = 0,
     };
 }
 
