@@ -107,6 +107,7 @@ def main():
                     help="rejection (default): the reference's rejection loops, try by try; direct: PT_SAMPLER_DIRECT, the same "
                          "distributions without a loop (not in the reference; include/ptgpu.h).  The headline line is always the "
                          "reference-faithful default; at N = 1 it carries the direct mode's time beside it (`sampler_direct`)")
+    ap.add_argument("--dump-frame", default=None, help="tests: rank 0 saves the last step's fp32 sums (H x W x 3) to this .npy file")
     ap.add_argument("--no-extras", action="store_true", help="skip the scan_reference and sampler_direct frames (profiling runs)")
     ap.add_argument("--spheres", type=int, default=0,
                     help="0 (default) = scene 21, the headline config; N > 0 = the synthetic random-sphere scene of N spheres "
@@ -211,6 +212,9 @@ def main():
         dt_max = dt
     all_paths, all_rays = float(tot[1]), float(tot[2])
 
+    if rank == 0 and args.dump_frame:
+        import numpy as np
+        np.save(args.dump_frame, frame.detach().cpu().numpy().reshape(img.height, img.width, 3))
     if rank == 0:
         nsph = len(scene.spheres)
         scene_name = ("synthetic random-sphere scene (%d spheres, generator seed 1)" % nsph if args.spheres > 0
@@ -293,7 +297,7 @@ def main():
                                       4 * args.spp, "GPU" if weak else "frame", args.spp, args.depth),
                        "parallelism": "1 GPU" if world == 1 else
                                       ("sample-range split x%d" if args.split == "samples" else "interleaved 256-pixel tile split x%d") % world
-                                      + " + RCCL reduce(SUM) of fp32 sums",
+                                      + (" + gloo all_reduce(SUM) of fp32 sums (rehearsal: all ranks on one GPU)" if args.rehearse_gloo else " + RCCL reduce(SUM) of fp32 sums"),
                        "chunk": args.chunk, "global_paths_per_pixel": 4 * args.spp * (world if weak else 1),
                        "sampler": "direct (PT_SAMPLER_DIRECT: not the reference's rejection loops)" if sampler else "rejection (the reference's loops)"},
             "mrays_per_s": all_rays / dt_max * 1e-6,

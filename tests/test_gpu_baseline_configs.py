@@ -69,24 +69,29 @@ def test_config1_three_materials_full_frame(orc, gpu):
 
 
 def test_config2_headline_full_size_properties(orc, gpu):
-    """configs[2]: scene 21, 1920x1080, 1024 spp, depth 50 — full size."""
+    """configs[2]: scene 21, 1920x1080, 1024 spp, depth 50 — full size, in bench.py's own configuration: chunk 16 (the
+    primary pass's per-item masks and batched record reads), sphere tree, both candidate lists, one segment."""
     host, scene, cam = _setup(gpu, 21, 456)
     img = host.Image(1920)
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=256, rebounds=50)
-    full = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=64))
+    full = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=16))
     st = gpu.stats()
     assert st.paths == 1920 * 1080 * 1024 and 1.8 < st.rays / st.paths < 2.6 and st.not_unit == 0
+    assert st.primary_rays == st.paths and st.list2_rays > 0 and st.box_tests > 0   # lists for every camera ray, second-bounce lists, the tree: the shipped path
     mean = full / 1024.0
     assert 0.0 <= mean.min() and mean.max() <= 1.0 + 1e-6
     # run-to-run determinism (work stealing must not change a bit)
-    again = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=64))
+    again = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=16))
     np.testing.assert_array_equal(again, full)
     # pixel spot checks at the full sample count: oracle with the same chunking, 24 scattered pixels
     rng = np.random.default_rng(7)
     for idx in rng.integers(0, img.num_pixels, 24):
-        cfg = host.make_pt_config(img, rt, seed=456, chunk=64, istart=int(idx), istop=int(idx) + 1)
+        cfg = host.make_pt_config(img, rt, seed=456, chunk=16, istart=int(idx), istop=int(idx) + 1)
         ref, _ = _oracle_sum(orc, scene.spheres, cam.pod, cfg, nthreads=1)
         np.testing.assert_array_equal(full.reshape(-1, 3)[idx], ref.reshape(-1, 3)[idx])
+    # the same frame with the unmasked record path (chunk 64: every record is looked at) differs by fp32 add order only
+    other = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=64, istart=500 * 1920, istop=502 * 1920))
+    np.testing.assert_allclose(other[500:502], full[500:502], rtol=2e-5)
     # the reference's own summation order (one sequential fp32 sum of 1024 terms, chunk = 0) differs from
     # the chunked sum only by fp32 add order (a 1024-term sequential sum carries ~1e-5 relative rounding)
     seq = gpu.render_sum(host.make_pt_config(img, rt, seed=456, chunk=0, istart=1000 * 1920, istop=1001 * 1920))
@@ -94,6 +99,35 @@ def test_config2_headline_full_size_properties(orc, gpu):
     cfg = host.make_pt_config(img, rt, seed=456, chunk=0, istart=1000 * 1920 + 77, istop=1000 * 1920 + 78)
     ref, _ = _oracle_sum(orc, scene.spheres, cam.pod, cfg, nthreads=1)
     np.testing.assert_array_equal(seq[1000, 77], ref[1000, 77])  # and that order is the oracle's, bit for bit
+
+
+def test_n4_convergence_at_config0_frame_size(orc, gpu):
+    """North star N4 at configs[0]'s own frame (256x144): the GPU's 4096-path frame against the reference's own sequential
+    sampler (orc_render_sum_zig) at 256 paths per pixel — mse = sigma^2 (1/4096 + 1/256), so the PSNR must sit where two
+    unbiased estimates of one image put it (measured 48x27: 256 reference paths -> ~42 dB), and the GPU frame against an
+    independent oracle Philox frame of 512 paths per pixel likewise."""
+    host, scene, cam = _setup(gpu, 21, 456)
+    img = host.Image(256)
+    assert img.height == 144
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=1024, rebounds=50)
+    g = gpu.render_mean(host.make_pt_config(img, rt, seed=1, chunk=16)).astype(np.float64)
+    ocam = orc.Camera()
+    C.memmove(C.byref(ocam), C.byref(cam.pod), C.sizeof(ocam))
+    oimg = orc.image_new(256)
+    spheres, stream = orc.setup_scene(21, 456)
+    ocfg = orc.make_config(oimg, subpixels=4, rays_per_subsample=64, rebounds=50, mode=2)
+    rc, s, stz = orc.render_sum_zig(spheres, ocam, ocfg, stream)      # single thread, as main.zig:166-177 (~10 s)
+    assert rc == 0 and stz.paths == 256 * 144 * 256
+    z = orc.resolve_mean(ocfg, s).astype(np.float64)
+    psnr_ref = 10.0 * np.log10(1.0 / float(np.mean((g - z) ** 2)))
+    pcfg = orc.make_config(oimg, subpixels=4, rays_per_subsample=128, rebounds=50, mode=0, seed=2)
+    rc, s, _ = orc.render_sum(spheres, ocam, pcfg, nthreads=32)
+    assert rc == 0
+    p = orc.resolve_mean(pcfg, s).astype(np.float64)
+    psnr_phi = 10.0 * np.log10(1.0 / float(np.mean((g - p) ** 2)))
+    # two estimates with n1 and n2 paths: expected PSNR difference 10 log10((1/4096 + 1/256) / (1/4096 + 1/512)) = 2.7 dB
+    assert psnr_ref >= 38.0 and psnr_phi >= 40.0, (psnr_ref, psnr_phi)
+    assert 1.5 < psnr_phi - psnr_ref < 4.0, (psnr_ref, psnr_phi)
 
 
 def test_config3_sample_range_split_4k(gpu):

@@ -77,6 +77,7 @@ def test_config4_one_rank_tile_share_100k_spheres(orc, gpu):
     flat = got.reshape(-1, 3)
     mine = (np.arange(img.num_pixels) // tile) % owners == owner
     assert st.paths == int(mine.sum()) * 256 and st.not_unit == 0
+    assert st.primary_rays > 0 and st.box_tests > 0    # lists built by pt_primary_lists<true>'s tree walk, megakernel through the tree
     assert not flat[~mine].any() and flat[mine].any(axis=1).all()
     rng = np.random.default_rng(44)
     ocam = orc.Camera()

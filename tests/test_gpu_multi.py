@@ -114,3 +114,44 @@ def test_pt_render_cli_gpus_flag(tmp_path):
     assert b"RCCL reduce" in r.stderr
     ref = open(one, "rb").read()
     assert ref.startswith(b"P3\n96 54\n255\n") and open(multi_t, "rb").read() == ref and open(multi_s, "rb").read() == ref
+
+
+@pytest.mark.parametrize("split", ["tiles", "samples"])
+def test_bench_two_ranks_on_one_gpu_assemble_the_one_gpu_frame(gpu, split, tmp_path):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank), rehearsed with both
+    ranks on the one GPU over gloo: rank 0's frame after the collective is the one-GPU frame — bit for bit under the tile
+    split, the two sample halves added under the sample split — and the JSON line says what ran."""
+    import json
+    import socket
+    import sys
+    from path_tracer_amd import host
+    from path_tracer_amd.gpu import multi_plan
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frame.npy")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "480",
+           "--spp", "4", "--split", split, "--rehearse-gloo", "--dump-frame", out]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, check=True, timeout=280, capture_output=True, env=env, cwd=ROOT)
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "rehearsal" in line
+    assert ("tile split x2" if split == "tiles" else "sample-range split x2") in line["config"]["parallelism"]
+    assert "gloo" in line["config"]["parallelism"] and "RCCL" not in line["config"]["parallelism"]
+    assert "480x270" in line["metric"] and "16 spp" in line["metric"] and line["metric"] != "paths/sec (scene 21, 1920x1080, 1024 spp, depth 50)"
+    assert line["config"]["global_paths_per_pixel"] == 16 and "cpu_baseline" not in line
+    got = np.load(out)
+    scene = host.Scene().setupScene(456, 21)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(host.Camera.preset(21).pod)
+    img = host.Image(480)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=4, rebounds=50)
+    chunk = line["config"]["chunk"]
+    whole = host.make_pt_config(img, rt, seed=456, chunk=chunk)
+    if split == "tiles":
+        want = gpu.render_sum(whole)
+        assert abs(line["value"] * line["ms_per_step"] * 1e-3 - img.num_pixels * 16) < 1.0   # all ranks' paths over the slowest rank's time
+    else:
+        want = gpu.render_sum(multi_plan(whole, "samples", 2, 0)) + gpu.render_sum(multi_plan(whole, "samples", 2, 1))
+    np.testing.assert_array_equal(got, want)
