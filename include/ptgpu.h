@@ -245,6 +245,12 @@ enum {
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);
 
+/* Proof by exhaustion of the library's lean correctly rounded f32 sequences (csrc/pt_device.h: v_sqrt_f32 / v_rcp_f32 plus
+ * one FMA correction instead of the compiler's longer expansions): all 2^32 bit patterns through the lean sequence and
+ * through the compiler's expression; *mismatches must come back 0.  which: 0 sqrtf(x), 1 1.0f / x, 2 1.0f / sqrtf(x)
+ * (vec3.zig:61-64 unitVector), 3 the unit-length test of illumination.zig:28 taken on |d|^2.  About 0.1 s each. */
+int ptgpu_debug_exhaustive(ptgpu_ctx *ctx, int which, uint64_t *mismatches);
+
 /* ---- multi-GPU: the GPUs of one node behind one handle ---------------------------------
  * Replaces the reference's thread block, main.zig:142-165 (T threads over contiguous pixel chunks of
  * multithreading.zig:40-44, then join): one host thread per GPU drives that GPU's own context and

@@ -20,14 +20,61 @@ __device__ __forceinline__ V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y,
 __device__ __forceinline__ V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 vmul(V3 a, float k) { return v3(k * a.x, k * a.y, k * a.z); }
 __device__ __forceinline__ V3 vemul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// ---- correctly rounded sqrt / reciprocal in fewer issue slots ----------------------------------------------------------
+// The reference's arithmetic needs IEEE-correct sqrt and division (the oracle is gcc on the CPU).  The compiler's sequences
+// for them (-fhip-fp32-correctly-rounded-divide-sqrt) cost 19 and 15 FMA issue slots (tools/op_cost_bench.hip): they scale
+// denormal / extreme operands first and fix special values last.  For operands in 2^-96 <= x < 2^96 none of that applies, and
+// the core is: v_sqrt_f32 (1 ulp) + the compiler's own one-ulp-up / one-ulp-down residual test; v_rcp_f32 (1 ulp) + one
+// Newton step in FMA.  Operands outside the range (and negative, zero, infinite, NaN ones) take the compiler's sequence.
+// PROVEN BY EXHAUSTION: every one of the 2^32 bit patterns gives the same bits as sqrtf(x), 1.0f / x and 1.0f / sqrtf(x)
+// (tools/exhaustive_math.hip; re-checked on every GPU test run through PT_FN_EXHAUSTIVE_*, tests/test_gpu_lean_math.py).
+__device__ __forceinline__ bool lean_range_sqrt(float x) { return __float_as_uint(x) - 0x0f800000u < 0x70000000u; } // 2^-96 <= x < inf
+__device__ __forceinline__ bool lean_range_rcp(float x) { return __float_as_uint(x) - 0x0f800000u < 0x60000000u; }  // 2^-96 <= x < 2^96
+__device__ __forceinline__ float sqrt_core(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-dn, s, x), vs = __builtin_fmaf(-up, s, x);
+    s = (vp <= 0.0f) ? dn : s;
+    s = (vs > 0.0f) ? up : s;
+    return s;
+}
+__device__ __forceinline__ float rcp_core(float s) {
+    const float r = __builtin_amdgcn_rcpf(s);
+    return __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+}
+#ifndef PT_LEAN_MATH
+#define PT_LEAN_MATH 1 // 0: the compiler's sequences everywhere (A/B builds)
+#endif
+__device__ __forceinline__ float sqrt_rn(float x) {          // == sqrtf(x)
+    if (PT_LEAN_MATH && lean_range_sqrt(x)) return sqrt_core(x);
+    return sqrtf(x);
+}
+__device__ __forceinline__ float rcp_rn(float x) {           // == 1.0f / x
+    if (PT_LEAN_MATH && lean_range_rcp(x)) return rcp_core(x);
+    return 1.0f / x;
+}
+__device__ __forceinline__ float inv_sqrt_rn(float x) {      // == 1.0f / sqrtf(x): two roundings, as vec3.zig:61-64 takes them
+    if (PT_LEAN_MATH && lean_range_sqrt(x)) return rcp_core(sqrt_core(x));
+    return 1.0f / sqrtf(x);
+}
+// illumination.zig:28's test |sqrt(a) - 1| > 1e-5 on a = |d|^2 (>= 0 or NaN) without the square root: sqrt is monotone, so the
+// test is two comparisons of a against the f32 thresholds where it flips (found and checked by exhaustion, as above)
+__device__ __forceinline__ bool not_unit_len2(float a) {
+#if PT_LEAN_MATH
+    return a < __uint_as_float(0x3f7ffeb2u) || a > __uint_as_float(0x3f8000a7u);
+#else
+    return fabsf(sqrtf(a) - 1.0f) > 0.00001f;
+#endif
+}
+
 // vec3.zig:67-69: left-to-right sum of products, no FMA
 __device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // vec3.zig:37-39: pow(x,2)+pow(y,2)+pow(z,2); Zig's pow(x,2) is x*x (mantissa square, one rounding)
 __device__ __forceinline__ float vlen2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ float vlen(V3 a) { return sqrtf(vlen2(a)); } // vec3.zig:30-32
+__device__ __forceinline__ float vlen(V3 a) { return sqrt_rn(vlen2(a)); } // vec3.zig:30-32
 // vec3.zig:61-64: multiply by the reciprocal of the norm
 __device__ __forceinline__ V3 vunit(V3 a) {
-    const float inv_n = 1.0f / vlen(a);
+    const float inv_n = inv_sqrt_rn(vlen2(a));
     return v3(inv_n * a.x, inv_n * a.y, inv_n * a.z);
 }
 
@@ -48,7 +95,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // three-way XOR in ONE instruction: gfx950's v_bitop3_b32 with truth table 0x96 (a ^ b ^ c); the compiler emits two
+        // v_xor_b32 for the C expression.  Measured (tools/op_cost_bench.hip): a Philox block 77 -> 60 FMA-issue-equivalents.
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -182,7 +231,7 @@ __device__ __forceinline__ V3 direct_vector_in_unit_disk(float xi0, float xi1) {
     sincos_quarter(q - (float)k, s, c);
     const float cx = (k == 0u) ? c : (k == 1u) ? -s : (k == 2u) ? -c : s;
     const float sy = (k == 0u) ? s : (k == 1u) ? c : (k == 2u) ? -s : -c;
-    const float rr = sqrtf(xi0);
+    const float rr = sqrt_rn(xi0);
     return v3(rr * cx, rr * sy, 0.0f);
 }
 // uniform in the positive octant of the unit ball (the distribution of material.zig:27-34): direction with z = xi0
@@ -190,7 +239,7 @@ __device__ __forceinline__ V3 direct_vector_in_unit_disk(float xi0, float xi1) {
 __device__ __forceinline__ V3 direct_vector_in_unit_sphere(float xi0, float xi1, float xi2) {
     float s, c;
     sincos_quarter(xi1, s, c);
-    const float sxy = sqrtf(1.0f - xi0 * xi0);
+    const float sxy = sqrt_rn(1.0f - xi0 * xi0);
     const float rho = cbrt_unit(xi2);
     return v3(rho * (sxy * c), rho * (sxy * s), rho * xi0);
 }
@@ -265,7 +314,7 @@ __device__ __forceinline__ bool sphere_near_root(V3 o, V3 d, float a, float cx, 
     // t > t_min for any t_min >= 0 (NaN operands fail it too) — the sphere is behind the origin, or the ray
     // is leaving its surface.  About half of the filter's survivors end here, before the sqrt and the divide.
     if (t_min >= 0.0f && half_b >= 0.0f) return false;
-    const float sqrtd = sqrtf(discriminant);
+    const float sqrtd = sqrt_rn(discriminant);
     const float t = (-half_b - sqrtd) / a;
     if (t < t_max && t > t_min) { t_out = t; return true; }
     return false;
@@ -294,7 +343,7 @@ __device__ __forceinline__ bool refract(V3 d, V3 n, float n1_over_n2, V3 &out) {
     const V3 r_perpendicular = vmul(vadd(d, vmul(n, cos_theta)), n1_over_n2);
     const float discriminant = 1.0f - vlen2(r_perpendicular);
     if (discriminant < 0.0f) return false;
-    const V3 r_parallel = vmul(n, -1.0f * sqrtf(discriminant));
+    const V3 r_parallel = vmul(n, -1.0f * sqrt_rn(discriminant));
     out = vadd(r_perpendicular, r_parallel);
     return true;
 }
@@ -320,10 +369,10 @@ __device__ __forceinline__ float schlick(float cosine, float refraction_index) {
 //
 // Per-sphere and per-ray values the reference recomputes at every hit are passed in: inv_param =
 // 1/refraction_index and r0 = schlick_r0(refraction_index) (dielectrics only; the scene tables
-// hold them), d_len = |d| (the caller already has |d|^2).  Each is the f32 value the reference's
-// own expression yields, so the result is unchanged.
+// hold them), len2 = |d|^2 (the caller has it; |d| is taken where a dielectric needs it).  Each is the f32 value the
+// reference's own expression yields, so the result is unchanged.
 template <bool DIRECT = false, class R>
-__device__ __forceinline__ V3 scatter_pre(uint32_t kind, float param, float inv_param, float r0, float d_len, V3 d, V3 p, V3 n,
+__device__ __forceinline__ V3 scatter_pre(uint32_t kind, float param, float inv_param, float r0, float len2, V3 d, V3 p, V3 n,
                                           R &r) {
     V3 out;
     if (kind != 2u) {
@@ -342,6 +391,7 @@ __device__ __forceinline__ V3 scatter_pre(uint32_t kind, float param, float inv_
         V3 outward_normal;
         float n1_over_n2, cosine;
         const float dn = vdot(d, n);
+        const float d_len = sqrt_rn(len2); // vlen(ray.direction), material.zig:140,144
         if (dn > 0.0f) {
             outward_normal = vunit(v3(-n.x, -n.y, -n.z));
             n1_over_n2 = param;
@@ -365,16 +415,16 @@ __device__ __forceinline__ V3 scatter_pre(uint32_t kind, float param, float inv_
 
 template <class R>
 __device__ __forceinline__ V3 scatter(uint32_t kind, float param, V3 d, V3 p, V3 n, R &r) {
-    return scatter_pre(kind, param, 1.0f / param, schlick_r0(param), vlen(d), d, p, n, r);
+    return scatter_pre(kind, param, 1.0f / param, schlick_r0(param), vlen2(d), d, p, n, r);
 }
 
-// illumination.zig:27-34; returns false for DirectionIsNotUnitVector.  len_u = |u|.
-__device__ __forceinline__ bool lerp_sky_len(V3 u, float len_u, V3 p0, V3 p1, V3 &out) {
-    if (fabsf(len_u - 1.0f) > 0.00001f) return false; // constants.zig:3
+// illumination.zig:27-34; returns false for DirectionIsNotUnitVector.  len2_u = |u|^2.
+__device__ __forceinline__ bool lerp_sky_len2(V3 u, float len2_u, V3 p0, V3 p1, V3 &out) {
+    if (not_unit_len2(len2_u)) return false; // |sqrt(len2) - 1| > epsilon, constants.zig:3
     const float t = (u.y + 1.0f) * 0.5f;
     out = vadd(vmul(p0, 1.0f - t), vmul(p1, t));
     return true;
 }
-__device__ __forceinline__ bool lerp_sky(V3 u, V3 p0, V3 p1, V3 &out) { return lerp_sky_len(u, vlen(u), p0, p1, out); }
+__device__ __forceinline__ bool lerp_sky(V3 u, V3 p0, V3 p1, V3 &out) { return lerp_sky_len2(u, vlen2(u), p0, p1, out); }
 
 } // namespace ptdev

@@ -90,7 +90,7 @@ constexpr uint32_t kHitMask = (1u << kTagShift) - 1u;
 constexpr uint32_t kDrawBits = 13;  // STATE2 packs (draws taken, second hit id) into the second half's .w: 13 + 19 bits
 #define kNaN __builtin_nanf("")
 
-enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_BOX_TESTS = 15, CNT_PRIMARY_CANDS = 20, CNT_N = 24 }; // 8..13, 16..19: PT_PHASE_TIMING builds; CNT_N-1: resolve's clamp count
+enum { CNT_QUEUE = 0, CNT_PATHS = 1, CNT_RAYS = 2, CNT_CANDS = 3, CNT_NOT_UNIT = 4, CNT_WAVE_STEPS = 5, CNT_FLUSH_ITERS = 6, CNT_PRIMARY_RAYS = 7, CNT_LIST2_RAYS = 14, CNT_BOX_TESTS = 15, CNT_PRIMARY_CANDS = 20, CNT_CLAMPED = 23, CNT_PP0 = 24, CNT_N = 32 }; // 8..13, 16..19, CNT_PP0..+7: PT_PHASE_TIMING builds; CNT_CLAMPED: resolve's clamp count
 
 // x / d for any u32 x without the ~35-instruction expansion of a run-time integer division: mulhi by a
 // host-computed magic number (the "branch-free" scheme: t = mulhi(x, M); q = (t + ((x - t) >> 1)) >> s).
@@ -161,6 +161,7 @@ struct KParams {
     const uint32_t *tprim;
     uint32_t troot, tnode_count;
     uint32_t tree_exit_at; // a ray step's walk ends once at most this many lanes are still walking (0: when none is)
+    uint32_t tree_flush_at; // the walk tests its postponed leaves once this many lanes hold one
 };
 
 // Pixel index of local slot `po`: the range itself, or the owner's interleaved tiles
@@ -475,41 +476,64 @@ struct TreeInLds {
 // stack lives in LDS), closest / hit its result so far.  exit_at > 0: the wave leaves the loop as soon as at most that many
 // lanes are still walking, provided some lane has finished (the megakernel then shades the finished lanes and gives
 // them their next rays while the stragglers keep their place; they go on in the next ray step).  exit_at = 0: to the end.
+#ifdef PT_WALK_PROFILE // diagnostic build (tools/build_variant.sh walkprof -DPT_WALK_PROFILE): lanes per walk-loop iteration by what they do
+static __device__ unsigned long long g_walk_prof[8];
+#endif
 template <class Tree>
-__device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t exit_at, uint32_t tid, V3 o, V3 d, float a, float t_min, float t_max,
-                                                  float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters, uint32_t &n_boxes) {
+__device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t &pend, uint32_t exit_at, uint32_t flush_at, uint32_t tid, V3 o, V3 d, float a,
+                                                  float t_min, float t_max, float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters, uint32_t &n_boxes) {
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     // (a lane without a ray stays out — the caller gives it cur = kNone: its parked NaN direction would pass every box, min/max drop NaN operands)
-    const unsigned long long walking0 = __ballot(cur != Tree::kNone || sp > 0u);
-    // One loop, both bodies: a lane holding a leaf tests its spheres in the same iteration in which others test boxes.
-    // (Measured against "while-while" — inner nodes until every lane holds a leaf, then the leaves together: 63 vs 75 ms on
-    // the 100 000-sphere scene, 43.5 vs 43.1 on 3 000 spheres, 30.2 vs 29.0 on scene 21 forced through the tree.)
+    const unsigned long long walking0 = __ballot(cur != Tree::kNone || sp > 0u || pend != Tree::kNone);
+    // One loop serves inner nodes and leaves (measured against "while-while" — inner nodes until every lane holds a leaf, then the
+    // leaves together: 63 vs 75 ms on the 100 000-sphere scene, 43.5 vs 43.1 on 3 000 spheres, 30.2 vs 29.0 on scene 21).
+    // LEAVES ARE POSTPONED: with every leaf tested where it is met, 59 % of the iterations ran the leaf body for 12 of 64 lanes
+    // (scene 21; PT_WALK_PROFILE build).  A lane that reaches a leaf parks it in `pend` and goes on with its stack; the parked
+    // leaves are tested together once `flush_at` lanes hold one (or no lane has an inner node left).  The order in which spheres
+    // are tested does not matter for the result — the closest hit is the minimum of (t, index) over every sphere that is tested,
+    // and a box is only ever skipped against the closest hit found SO FAR, which a later test can only lower.
     for (;;) {
         if (cur == Tree::kNone && sp > 0u) cur = T.pop(--sp, tid);
-        const unsigned long long walking = __ballot(cur != Tree::kNone);
+        if (cur != Tree::kNone && (cur & Tree::kLeafBit) && pend == Tree::kNone) {
+            pend = cur;
+            cur = Tree::kNone;
+            if (sp > 0u) cur = T.pop(--sp, tid);
+        }
+        const bool at_inner = cur != Tree::kNone && !(cur & Tree::kLeafBit);
+        const unsigned long long m_inner = __ballot(at_inner), m_pend = __ballot(pend != Tree::kNone);
+        const unsigned long long walking = m_pend | __ballot(cur != Tree::kNone);
         if (walking == 0ull) break;
         if (exit_at != 0u && walking != walking0 && (uint32_t)__popcll(walking) <= exit_at) break;
         n_iters++;
-        if (cur == Tree::kNone) {
-            // nothing pending for this lane: it waits for the wave
-        } else if (cur & Tree::kLeafBit) {
-            const uint32_t first = Tree::first(cur), cnt = Tree::count(cur);
+#ifdef PT_WALK_PROFILE
+        if ((tid & 63u) == 0u) {
+            const bool fl = (uint32_t)__popcll(m_pend) >= flush_at || m_inner == 0ull;
+            atomicAdd(&g_walk_prof[0], fl ? (unsigned long long)__popcll(m_pend) : 0ull); atomicAdd(&g_walk_prof[1], (unsigned long long)__popcll(m_inner));
+            atomicAdd(&g_walk_prof[2], fl ? 1ull : 0ull); atomicAdd(&g_walk_prof[3], m_inner ? 1ull : 0ull);
+            atomicAdd(&g_walk_prof[4], 1ull);
+        }
+#endif
+        if ((uint32_t)__popcll(m_pend) >= flush_at || m_inner == 0ull) { // wave-uniform
+            if (pend != Tree::kNone) {
+                const uint32_t first = Tree::first(pend), cnt = Tree::count(pend);
 #pragma unroll
-            for (uint32_t k = 0; k < kTreeLeaf; ++k) {
-                if (k < cnt) {
-                    float4 g; uint32_t id;
-                    T.sphere(first + k, g, id);
-                    n_cands++;
-                    float t;
-                    if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
-                        // the scan's outcome: smallest t, and among equal t the lowest sphere index
-                        if (t < closest || (t == closest && (int)id < hit)) { closest = t; hit = (int)id; }
+                for (uint32_t k = 0; k < kTreeLeaf; ++k) {
+                    if (k < cnt) {
+                        float4 g; uint32_t id;
+                        T.sphere(first + k, g, id);
+                        n_cands++;
+                        float t;
+                        if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
+                            // the scan's outcome: smallest t, and among equal t the lowest sphere index
+                            if (t < closest || (t == closest && (int)id < hit)) { closest = t; hit = (int)id; }
+                        }
                     }
                 }
+                pend = Tree::kNone;
             }
-            cur = Tree::kNone;
-        } else {
+        }
+        if (at_inner) {
             float4 A, B, C; uint32_t c0, c1;
             T.node(cur, A, B, C, c0, c1);
             float n0, n1;
@@ -617,7 +641,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
     V3 o = v3(0.f, 0.f, 0.f), d = v3(kNaN, kNaN, kNaN); // parked (see phase A) until the first path starts
     uint32_t bounce = 0;
     // tree variants: the lane's walk (it may span ray steps, see scene_is_hit_tree) and its result so far
-    uint32_t t_cur = TREE_LDS ? TreeInLds::kNone : TreeInGlobal::kNone, t_sp = 0;
+    uint32_t t_cur = TREE_LDS ? TreeInLds::kNone : TreeInGlobal::kNone, t_sp = 0, t_pend = t_cur;
     float t_closest = 0.f;
     int t_hit = -1;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
@@ -781,18 +805,18 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
         bool tracing = alive && !need_path; // the lane has a ray in flight (not dead, not idling on an empty item)
         if (TREE) {
             constexpr uint32_t kNone = TREE_LDS ? TreeInLds::kNone : TreeInGlobal::kNone;
-            const bool walking = t_cur != kNone || t_sp != 0u;
+            const bool walking = t_cur != kNone || t_sp != 0u || t_pend != kNone;
             if (tracing && !walking) { // a new ray: start its walk
                 t_cur = TREE_LDS ? TreeInLds::ref16(P.troot) : P.troot;
                 t_closest = P.t_max; t_hit = -1;
             }
             if (TREE_LDS)
-                scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
-                                  t_hit, n_cands, n_flush_iters, n_boxes);
+                scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max,
+                                  t_closest, t_hit, n_cands, n_flush_iters, n_boxes);
             else
-                scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, P.tree_exit_at, tid, o, d, a, P.t_min, P.t_max, t_closest, t_hit,
-                                  n_cands, n_flush_iters, n_boxes);
-            tracing = tracing && t_cur == kNone && t_sp == 0u; // lanes still walking skip this step's shading and keep their ray
+                scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
+                                  t_hit, n_cands, n_flush_iters, n_boxes);
+            tracing = tracing && t_cur == kNone && t_sp == 0u && t_pend == kNone; // lanes still walking skip this step's shading and keep their ray
             closest = t_closest; hit = t_hit;
         } else
             scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
@@ -804,7 +828,6 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
 
         // ---- phase C: radiance step (illumination.zig:76-90) ---------------------
         if (tracing) {
-            const float d_len = sqrtf(a); // |d|: lerp's unit check (illumination.zig:28) and Dielectric's cosine (material.zig:140,144)
             bool done = false;
             V3 color = v3(0.f, 0.f, 0.f);
             bool ok = true;
@@ -830,7 +853,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
                     PT_STAMP(tH0);
                     sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
                     PT_STAMP(tH1);
-                    const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                    const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, a, d, p, n, rng); // (a = |d|^2: lerp's unit check and the dielectric's cosine take |d| from it)
                     PT_STAMP(tH2);
                     PT_SUB_ACC(0, tH0, tH1); PT_SUB_ACC(1, tH1, tH2);
 #ifndef PT_EXPERIMENT_NO_STACK // tools/build_variant.sh timing experiment (breaks parity)
@@ -841,7 +864,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
                 }
             } else {
                 PT_STAMP(tM0);
-                ok = lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color); // illumination.zig:88
+                ok = lerp_sky_len2(d, a, P.blend_start, P.blend_stop, color); // illumination.zig:88
                 // v.elementwiseMul(s.attenuation), innermost first (illumination.zig:84-85)
                 for (uint32_t b = bounce; b > 0; --b) {
 #ifndef PT_EXPERIMENT_NO_STACK
@@ -1327,7 +1350,15 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
     // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
     uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0;
+#ifdef PT_PHASE_TIMING
+    unsigned long long t_pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // path start, list trace, shade, record write, whole
+    const unsigned long long tpp_begin = __builtin_amdgcn_s_memtime();
+#define PP_ACC(i, a, b) t_pp[i] += (b) - (a)
+#else
+#define PP_ACC(i, a, b)
+#endif
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
+        PT_STAMP(tq0);
         const uint32_t item = P.div_chunk.div(r), jj = r - item * P.chunk;
         const uint32_t k = P.div_npix.div(item), po = item - k * P.npix;
         const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
@@ -1357,10 +1388,13 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             // the record if nothing below gets further: the camera ray itself
             float4 ra = make_float4(o.x, o.y, o.z, __uint_as_float(kTagState0 << kTagShift));
             float4 rb = make_float4(d.x, d.y, d.z, __uint_as_float(rng.drawn()));
+            PT_STAMP(tq1);
+            PP_ACC(0, tq0, tq1);
             if (listed) {
                 uint32_t hit0 = 0;
                 // depth 0: the camera ray over list A; depth 1: the ray scattered off the pixel's main sphere over list B
                 for (uint32_t depth = 0;; ++depth) {
+                    PT_STAMP(tl0);
                     const uint32_t *Ld = depth ? L + kListB : L;
                     const float a = vlen2(d); // sphere.zig:68
                     float closest = P.t_max;
@@ -1387,7 +1421,8 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                         }
                     }
                     if (depth) rays2++; else rays++;
-                    const float d_len = sqrtf(a);
+                    PT_STAMP(tl1);
+                    PP_ACC(1 + (depth ? 2 : 0), tl0, tl1);
                     V3 color = v3(0.f, 0.f, 0.f);
                     uint32_t tag = kTagFinal;
                     if (hit >= 0) {
@@ -1406,8 +1441,10 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                             const uint32_t kind = kind_of((uint32_t)hit);
                             V3 p, n;
                             sphere_hit_point_inv(o, d, closest, g.x, g.y, g.z, inv_radius_of((uint32_t)hit), p, n);
-                            const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, d_len, d, p, n, rng);
+                            const V3 nd = scatter_pre<DIRECT>(kind, m.w, m.x, m.y, a, d, p, n, rng);
                             const uint32_t drawn = rng.drawn();
+                            PT_STAMP(tl2);
+                            PP_ACC(2 + (depth ? 2 : 0), tl1, tl2);
                             if (depth == 0u) {
                                 hit0 = (uint32_t)hit;
                                 ra = make_float4(p.x, p.y, p.z, __uint_as_float((kTagState1 << kTagShift) | hit0));
@@ -1426,7 +1463,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                             } else rays2--; // the record stays the one after the first bounce; the megakernel repeats (and counts) this step
                             break;
                         }
-                    } else if (!lerp_sky_len(d, d_len, P.blend_start, P.blend_stop, color)) { // illumination.zig:88
+                    } else if (!lerp_sky_len2(d, a, P.blend_start, P.blend_stop, color)) { // illumination.zig:88
                         tag = kTagSkip;
                         not_unit++;
                     } else if (depth) {
@@ -1438,8 +1475,11 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                     break;
                 }
             }
+            PT_STAMP(tw0);
             P.rec[2u * (size_t)r] = ra;
             if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
+            PT_STAMP(tw1);
+            PP_ACC(5, tw0, tw1);
             look = (__float_as_uint(ra.w) >> kTagShift) != kTagFinal;
         }
         if (P.use_mask) { // 64 % chunk == 0: an item's samples sit in one wave, lanes [lane - jj, lane - jj + chunk)
@@ -1447,6 +1487,12 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             if (jj == 0u) P.item_mask[item] = (uint32_t)(m >> (threadIdx.x & 63u)) & (uint32_t)((1ull << P.chunk) - 1ull);
         }
     }
+#ifdef PT_PHASE_TIMING
+    if ((threadIdx.x & 63u) == 0u) {
+        t_pp[7] = __builtin_amdgcn_s_memtime() - tpp_begin;
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[CNT_PP0 + i], t_pp[i]);
+    }
+#endif
     const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
     if ((threadIdx.x & 63u) == 0u) {
         if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays + w_rays2); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
@@ -1500,7 +1546,7 @@ __global__ void pt_resolve(const float *rgb_sum, uint32_t idx_start, uint32_t np
         // reference's ReleaseFast build — clamped here and counted.
         uint32_t v;
         if (!(col > 0.0f)) v = 0u;
-        else if (col > max_val_f) { v = 255u; atomicAdd(&counters[CNT_N - 1], 1ull); } // renderers/ppm_image.zig:76 asserts col <= 255
+        else if (col > max_val_f) { v = 255u; atomicAdd(&counters[CNT_CLAMPED], 1ull); } // renderers/ppm_image.zig:76 asserts col <= 255
         else v = (uint32_t)col;
         q[c] = v;
     }
@@ -1601,6 +1647,24 @@ __global__ void pt_debug_filter_bit(const float *in, const float *thr, float *ou
     out[(size_t)i * 3 + 2] = (thr[i] <= Fy) ? 1.0f : 0.0f;
 }
 
+// ptgpu_debug_exhaustive: the lean unary sequences of pt_device.h (sqrt_rn, rcp_rn, inv_sqrt_rn, not_unit_len2) against the
+// compiler's correctly rounded expressions on ALL 2^32 bit patterns; counts the patterns that differ (NaN == NaN).
+__global__ void pt_debug_exhaustive(int which, unsigned long long *bad) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x; // the low 24 bits
+    uint32_t n = 0;
+    for (uint32_t hi = 0; hi < 256u; ++hi) {
+        const uint32_t bits = (hi << 24) | tid;
+        const float x = __uint_as_float(bits);
+        float lean = 0.f, ref = 0.f;
+        if (which == 0) { lean = sqrt_rn(x); ref = sqrtf(x); }
+        else if (which == 1) { lean = rcp_rn(x); ref = 1.0f / x; }
+        else if (which == 2) { lean = inv_sqrt_rn(x); ref = 1.0f / sqrtf(x); }
+        else if (!(bits >> 31)) { lean = not_unit_len2(x) ? 1.f : 0.f; ref = (fabsf(sqrtf(x) - 1.0f) > 0.00001f) ? 1.f : 0.f; } // a = |d|^2: never negative
+        if (!(__float_as_uint(lean) == __float_as_uint(ref) || (lean != lean && ref != ref))) n++;
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
 // cast_ray and scatter consume random draws: the debug variants take the draws from
 // the input record (ArrayRng) so that the oracle can be fed the same numbers.
 __global__ void pt_debug_eval_rng(int fn, const float *in, float *out, uint32_t n, Cam cam) {
@@ -1668,7 +1732,7 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_filtered(const floa
 // PT_FN_SCENE_HIT_TREE: the same through the sphere tree (same record).
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *in, float *out, uint32_t n, const TreeNode *nodes, uint32_t n_nodes, const float4 *tgeom,
-                                                                  const uint32_t *tprim, uint32_t nspheres, uint32_t root, const float4 *g_geom, float t_min, float t_max) {
+                                                                  const uint32_t *tprim, uint32_t nspheres, uint32_t root, const float4 *g_geom, float t_min, float t_max, uint32_t flush_at) {
     __shared__ uint32_t s_stack[LDS ? 1 : kTreeStack * kBlock];
     __shared__ float4 s_tboxes[LDS ? 3 * kTreeLdsNodes : 1];
     __shared__ uint32_t s_tchild[LDS ? kTreeLdsNodes : 1];
@@ -1687,11 +1751,11 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     uint32_t n_cands = 0, n_iters = 0;
     uint32_t sp = 0, n_boxes = 0;
     if (LDS) {
-        uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone;
-        scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
+        uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone, pend = TreeInLds::kNone;
+        scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, pend, 0u, flush_at, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
     } else {
-        uint32_t cur = live ? root : kTreeNone;
-        scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, cur, sp, 0u, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
+        uint32_t cur = live ? root : kTreeNone, pend = kTreeNone;
+        scene_is_hit_tree(TreeInGlobal{nodes, tgeom, tprim, s_stack}, cur, sp, pend, 0u, flush_at, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
     }
     if (!live) return;
     float *w = out + (size_t)i * 8;
@@ -2440,6 +2504,10 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     // 3 000 spheres 41.1 / - / 37.2 / 37.2 / 37.6 / 38.5 / 40.3, 100 000 spheres 276.5 / - / 261.0 / 253.6 / 245.5 / 226.4 / 224.6.
     P.tree_exit_at = !multi ? 8u : (ctx->tree_nodes > 8192u ? 24u : 12u);
     { const char *e = getenv("PTGPU_TREE_EXIT_AT"); if (e) P.tree_exit_at = (uint32_t)atoi(e); } // A/B runs
+    // Postponed leaves are tested once this many lanes hold one.  Measured per 256 samples of 1080p, threshold 1 (every leaf where it is met) / 4 / 8 / 12 / 16 / 24 / 32 / 48:
+    // scene 21 in LDS 36.6 / 35.5 / 35.3 / 35.5 / 36.0 / 36.3 / 36.6 / 37.3 ms; 3 000 spheres 34.0 / - / 31.7 / - / 32.0 / 32.2; 100 000 spheres (64 samples) 68.8 / - / 65.4 / - / 63.9 / 63.9 / 73.6
+    P.tree_flush_at = (multi && ctx->tree_nodes > 8192u) ? 16u : 8u;
+    { const char *e = getenv("PTGPU_TREE_FLUSH_AT"); if (e) P.tree_flush_at = (uint32_t)atoi(e); } // A/B runs (1: every leaf where it is met, as before)
     P.primary = primary ? 1u : 0u;
     P.rec = primary ? reinterpret_cast<float4 *>(ctx->d_prim) : nullptr;
     uint32_t *d_lists = primary ? reinterpret_cast<uint32_t *>(ctx->d_prim + prim_rec_bytes) : nullptr;
@@ -2540,8 +2608,24 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         fprintf(stderr, "[phase timing] shader clock %.0f MHz (s_memtime / s_memrealtime)\n", tot / (double)h[13] * 100.0);
         fprintf(stderr, "[phase timing] share of wave cycles: refill %.3f  scan %.3f  (of which flush %.3f)  shade %.3f\n",
                 h[8] / tot, h[9] / tot, h[10] / tot, h[11] / tot);
+        if (h[CNT_PP0 + 7]) {
+            const double tp = (double)h[CNT_PP0 + 7];
+            fprintf(stderr, "[phase timing] pt_primary, share of its wave cycles: path start (Philox, jitter, lens, castRay) %.3f  list A %.3f  shade 0 (hit point, scatter) %.3f  "
+                            "list B %.3f  shade 1 %.3f  record write %.3f\n", h[CNT_PP0] / tp, h[CNT_PP0 + 1] / tp, h[CNT_PP0 + 2] / tp, h[CNT_PP0 + 3] / tp, h[CNT_PP0 + 4] / tp, h[CNT_PP0 + 5] / tp);
+        }
         fprintf(stderr, "[phase timing]   within shade: hit point %.3f  scatter %.3f  miss (lerp + unwinding) %.3f;  within refill: path start %.3f\n",
                 h[16] / tot, h[17] / tot, h[18] / tot, h[19] / tot);
+    }
+#endif
+#ifdef PT_WALK_PROFILE
+    {
+        unsigned long long wp[8];
+        if (hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_walk_prof), sizeof wp) == hipSuccess && wp[4]) {
+            fprintf(stderr, "[walk profile] loop iterations %llu: with a lane at a leaf %.3f (%.1f lanes each), with a lane at an inner node %.3f (%.1f lanes each)\n", wp[4],
+                    (double)wp[2] / wp[4], (double)wp[0] / (wp[2] ? wp[2] : 1), (double)wp[3] / wp[4], (double)wp[1] / (wp[3] ? wp[3] : 1));
+            memset(wp, 0, sizeof wp);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), wp, sizeof wp);
+        }
     }
 #endif
     ctx->stats.wave_steps = h[CNT_WAVE_STEPS];
@@ -2612,7 +2696,7 @@ extern "C" int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const 
     const uint32_t npix = cfg->idx_stop - cfg->idx_start;
     if (npix == 0) return PT_OK;
     const float k1 = 1.0f / (float)cfg->subpixels, k2 = 1.0f / (float)cfg->rays_per_subsample;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + (CNT_N - 1), 0, sizeof(unsigned long long), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + CNT_CLAMPED, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(pt_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, stream, d_rgb_sum, cfg->idx_start, npix, k1, k2,
                        (float)cfg->max_px_value, d_records, d_rgb8, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
@@ -2620,7 +2704,7 @@ extern "C" int ptgpu_resolve_device(ptgpu_ctx *ctx, const pt_config *cfg, const 
     // renderers/ppm_image.zig:75-77 asserts col <= 255 (and @floatToInt(u8) is undefined beyond it in
     // ReleaseFast): such values are written clamped to 255 and reported
     unsigned long long clamped = 0;
-    HIP_TRY(ctx, hipMemcpy(&clamped, ctx->d_counters + (CNT_N - 1), sizeof clamped, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&clamped, ctx->d_counters + CNT_CLAMPED, sizeof clamped, hipMemcpyDeviceToHost));
     return clamped ? PT_ERR_VALUE_EXCEEDS_MAX : PT_OK;
 }
 
@@ -2693,11 +2777,11 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
             if (ctx->n_pad <= (uint32_t)kTile) // the walk the megakernel would use for this scene: tree staged in LDS
                 hipLaunchKernelGGL(pt_debug_scene_hit_tree<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
                                    (const TreeNode *)ctx->d_tnodes, ctx->tree_nodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->nspheres,
-                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max);
+                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max, 8u);
             else
                 hipLaunchKernelGGL(pt_debug_scene_hit_tree<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
                                    (const TreeNode *)ctx->d_tnodes, ctx->tree_nodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->nspheres,
-                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max);
+                                   ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max, 8u);
         } else if (fn == PT_FN_SCENE_HIT_FILTERED) {
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)
@@ -2719,4 +2803,17 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     (void)hipFree(d_in); (void)hipFree(d_out);
     if (d_thr) (void)hipFree(d_thr);
     return rc;
+}
+
+extern "C" int ptgpu_debug_exhaustive(ptgpu_ctx *ctx, int which, uint64_t *mismatches) {
+    if (!ctx || !mismatches || which < 0 || which > 3) return PT_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(pt_debug_exhaustive, dim3((1u << 24) / 256u), dim3(256), 0, nullptr, which, ctx->d_counters);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    unsigned long long bad = 0;
+    HIP_TRY(ctx, hipMemcpy(&bad, ctx->d_counters, sizeof bad, hipMemcpyDeviceToHost));
+    *mismatches = bad;
+    return PT_OK;
 }

@@ -115,6 +115,12 @@ class GpuContext:
                                        float(t_max)), "ptgpu_debug_eval")
         return out
 
+    def debug_exhaustive(self, which):
+        """ptgpu_debug_exhaustive: mismatches of a lean f32 sequence against the compiler's over all 2^32 inputs (must be 0)"""
+        bad = C.c_uint64(1)
+        check(self._L.ptgpu_debug_exhaustive(self._h, int(which), C.byref(bad)), "ptgpu_debug_exhaustive")
+        return bad.value
+
     # ---- diagnostics -------------------------------------------------------------------
     def stats(self):
         st = pt_stats()
