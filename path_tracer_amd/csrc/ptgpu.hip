@@ -1380,6 +1380,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             cast_ray_from_disk(P.cam, u, v, disk, o, d);
             const uint32_t *L = P.lists + (size_t)po * kListStride;
             // a disk draw kept after PT_MAX_TRIES failed tries may lie outside the lens the list was built for
+            // (asking for the list before the path's draws, so that the loads run under them, costs 16 VGPRs and the sixth wave: 14.3 vs 14.2 ms)
 #ifdef PT_EXPERIMENT_TRIES1 // tools/build_variant.sh with -DPT_MAX_TRIES=1: what the rejection loops' retries cost this kernel (timing only, breaks parity)
             const bool listed = L[0] != kListOverflow;
 #else
@@ -1392,6 +1393,11 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             PP_ACC(0, tq0, tq1);
             if (listed) {
                 uint32_t hit0 = 0;
+                // the pixel's second-bounce header (sphere S, patch centre and radius^2, cone axis and cosine), fetched now with the
+                // list itself: asked for only when the first scatter is done, these loads were a round trip in the open
+                static_assert(kListS == 16 && kListP0 == 17 && kListRho2 == 20 && kListAxis == 21 && kListCos == 24, "header read as 2 x uint4 + 1");
+                const uint4 hd0 = reinterpret_cast<const uint4 *>(L)[4], hd1 = reinterpret_cast<const uint4 *>(L)[5];
+                const uint32_t hd_cos = L[kListCos];
                 // depth 0: the camera ray over list A; depth 1: the ray scattered off the pixel's main sphere over list B
                 for (uint32_t depth = 0;; ++depth) {
                     PT_STAMP(tl0);
@@ -1404,10 +1410,8 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                     const uint4 *L4 = reinterpret_cast<const uint4 *>(Ld);
                     const uint4 e0 = L4[0], e1 = L4[1], e2 = L4[2], e3 = L4[3];
                     const uint32_t ent[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
-                    bool more = true; // (a flag instead of a break: the sixteen steps unroll, ent[] stays in registers)
-#pragma unroll
-                    for (uint32_t i = 0; i < 16u; ++i) { // ascending sphere index, strict '<' (scene.zig:102)
-                        const uint32_t j = ent[i];
+                    bool more = true; // (a flag instead of a break: the steps unroll, ent[] stays in registers)
+                    auto test_entry = [&](uint32_t j) { // ascending sphere index, strict '<' (scene.zig:102)
                         more = more && j != kListEnd;
                         if (more) {
                             const float4 g = geom_of(j);
@@ -1419,6 +1423,13 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                                 if (t < closest || (MULTI_TILE && t == closest && (int)j < hit)) { closest = t; hit = (int)j; }
                             }
                         }
+                    };
+                    // four entries at a time; a group is skipped by the whole wave once every lane's list has ended (two to four spheres as a rule)
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        if (q > 0u && __ballot(more) == 0ull) continue;
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i) test_entry(ent[4u * q + i]);
                     }
                     if (depth) rays2++; else rays++;
                     PT_STAMP(tl1);
@@ -1451,9 +1462,9 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                                 rb = make_float4(nd.x, nd.y, nd.z, __uint_as_float(drawn));
                                 // one more bounce here if this ray is one list B was built for: it leaves the pixel's main sphere
                                 // within the patch and runs inside the cone
-                                const V3 dp = vsub(p, v3(__uint_as_float(L[kListP0]), __uint_as_float(L[kListP0 + 1]), __uint_as_float(L[kListP0 + 2])));
-                                const V3 axis = v3(__uint_as_float(L[kListAxis]), __uint_as_float(L[kListAxis + 1]), __uint_as_float(L[kListAxis + 2]));
-                                if (hit0 == L[kListS] && vlen2(dp) <= __uint_as_float(L[kListRho2]) && vdot(nd, axis) >= __uint_as_float(L[kListCos])) {
+                                const V3 dp = vsub(p, v3(__uint_as_float(hd0.y), __uint_as_float(hd0.z), __uint_as_float(hd0.w)));
+                                const V3 axis = v3(__uint_as_float(hd1.y), __uint_as_float(hd1.z), __uint_as_float(hd1.w));
+                                if (hit0 == hd0.x && vlen2(dp) <= __uint_as_float(hd1.x) && vdot(nd, axis) >= __uint_as_float(hd_cos)) {
                                     o = p; d = nd;
                                     continue;
                                 }
