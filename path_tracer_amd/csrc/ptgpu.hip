@@ -136,7 +136,8 @@ struct KParams {
     uint32_t s0, s1, chunk, nchunks; // sample range and chunking
     uint32_t nspheres;
     uint32_t total_threads;
-    FastDiv div_width, div_npix, div_chunk, div_tile; // divisions by width, npix, chunk, tile_pixels
+    FastDiv div_width, div_npix, div_chunk, div_tile, div_nchunks; // divisions by width, npix, chunk, tile_pixels, nchunks
+    uint32_t blocks_per_row; // pt_primary: 64-record blocks per chunk index (npix * chunk / 64) when that is whole, else 0
     const float4 *filt; // (cx, cz, threshold, cy) padded to a multiple of kPad
     uint32_t has_shared; // any shared-ordinate word in the scene
     const float *ycy;   // per 32-sphere mask word (padded to whole tiles): the cy all its spheres share, or NaN
@@ -147,8 +148,12 @@ struct KParams {
     float *part;        // direct ? frame[W*H][3] : [nchunks][npix][3] partial sums
     // primary pass (pt_primary): one record per path of the launch, index item * chunk + (sample - item's first sample)
     uint32_t primary;       // 1: the records exist; the megakernel starts its paths from them instead of casting camera rays
-    float4 *rec;            // record r = rec[2r], rec[2r+1]: (colour | origin, tag<<30 | first hit id), (direction, draws taken) — 32 B, so that
-                            // the two halves share a cache line and a line holds a lane's next record too
+    float4 *rec;            // record r = rec[2r], rec[2r+1]: (colour | origin, tag<<29 | first hit id), (direction, draws taken) — 32 B, so that
+                            // the two halves share a cache line and a line holds a lane's next record too.  (Round 3 tried the halves apart — first
+                            // halves dense, 16 B per path; second halves compacted per item: pt_primary wrote 47.5 instead of 68.9 GB per headline
+                            // frame, but the megakernel FETCHED 130 instead of 87 GB: a lane comes back to its item once per continued path, its
+                            // lines long evicted, and then pays one line per array — and ran exactly as fast, 78.1 vs 78.5 ms: the fetches are not
+                            // what it waits for.  Kept side by side.)
     uint32_t *item_mask;    // per item: bit j set = its sample j needs a look at its record (a state, or a dropped sample); clear = a finished
                             // colour.  use_mask = 0 (chunk does not divide 64, or > 32): not written, every record is looked at
     uint32_t use_mask;
@@ -1357,15 +1362,25 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
 #else
 #define PP_ACC(i, a, b)
 #endif
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nrec; r += gridDim.x * 256u) {
+    // A wave takes 64 consecutive records (whole items) per turn.  The order of the turns walks the CHUNKS OF A PIXEL GROUP before it moves to
+    // the next pixels (records are laid out chunk-major, item = chunk index * npix + pixel slot): the 176-byte candidate lists of those pixels
+    // are then fetched from memory once and found in the caches by the other chunks' waves, instead of once per chunk (64 times per frame:
+    // 24 GB of the headline frame's HBM reads, and the loads the candidate loop waits for).
+    const uint32_t nblocks = (nrec + 63u) >> 6, wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+    for (uint32_t v = wave0; v < nblocks; v += nwaves) {
         PT_STAMP(tq0);
+        uint32_t blk = v;
+        if (P.blocks_per_row) { const uint32_t pb = P.div_nchunks.div(v); blk = (v - pb * P.nchunks) * P.blocks_per_row + pb; }
+        const uint32_t r = (blk << 6) + (threadIdx.x & 63u);
         const uint32_t item = P.div_chunk.div(r), jj = r - item * P.chunk;
         const uint32_t k = P.div_npix.div(item), po = item - k * P.npix;
         const uint32_t pixel = slot_to_pixel(P.slot0 + po, P.idx_start, P.tile_pixels, P.tile_count, P.tile_index, P.div_tile);
         const uint32_t first = P.s0 + k * P.chunk;
         const uint32_t sample = first + jj;
         bool look = false; // the megakernel has to look at this path's record (a state to continue, or a dropped sample)
-        if (pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
+        if (r < nrec && pixel < P.idx_stop && sample < min(first + P.chunk, P.s1)) {
+            PT_STAMP(tq00);
+            PP_ACC(6, tq0, tq00);
             typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
             rng.init(P.seed_lo, P.seed_hi);
             rng.start_path(pixel, sample);
@@ -1489,13 +1504,13 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
             PT_STAMP(tw0);
             P.rec[2u * (size_t)r] = ra;
             if (__float_as_uint(ra.w) >> 31) P.rec[2u * (size_t)r + 1u] = rb;
+            look = (__float_as_uint(ra.w) >> kTagShift) != kTagFinal;
             PT_STAMP(tw1);
             PP_ACC(5, tw0, tw1);
-            look = (__float_as_uint(ra.w) >> kTagShift) != kTagFinal;
         }
         if (P.use_mask) { // 64 % chunk == 0: an item's samples sit in one wave, lanes [lane - jj, lane - jj + chunk)
             const unsigned long long m = __ballot(look);
-            if (jj == 0u) P.item_mask[item] = (uint32_t)(m >> (threadIdx.x & 63u)) & (uint32_t)((1ull << P.chunk) - 1ull);
+            if (jj == 0u && r < nrec) P.item_mask[item] = (uint32_t)(m >> (threadIdx.x & 63u)) & (uint32_t)((1ull << P.chunk) - 1ull);
         }
     }
 #ifdef PT_PHASE_TIMING
@@ -2503,7 +2518,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     P.tile_pixels = cfg->tile_pixels; P.tile_count = cfg->tile_count; P.tile_index = cfg->tile_index;
     P.direct = (nchunks == 1) ? 1u : 0u;
     P.s0 = s0; P.s1 = s1; P.chunk = chunk; P.nchunks = nchunks;
-    P.div_width = make_fastdiv(cfg->width); P.div_chunk = make_fastdiv(chunk); P.div_tile = make_fastdiv(cfg->tile_pixels ? cfg->tile_pixels : 1u);
+    P.div_width = make_fastdiv(cfg->width); P.div_nchunks = make_fastdiv(nchunks); P.div_chunk = make_fastdiv(chunk); P.div_tile = make_fastdiv(cfg->tile_pixels ? cfg->tile_pixels : 1u);
     P.nspheres = ctx->nspheres;
     P.total_threads = total_threads;
     P.filt = ctx->d_filt; P.ycy = ctx->d_ycy; P.has_shared = ctx->shared_tests ? 1u : 0u; P.geom = ctx->d_geom; P.mat = ctx->d_mat; P.kind = ctx->d_kind; P.inv_radius = ctx->d_inv_radius;
@@ -2535,6 +2550,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         P.slot0 = slot0;
         P.npix = std::min(seg, npix - slot0);
         P.div_npix = make_fastdiv(P.npix);
+        P.blocks_per_row = ((uint64_t)P.npix * chunk % 64u == 0u) ? (uint32_t)((uint64_t)P.npix * chunk / 64u) : 0u;
         if (slot0 != 0) HIP_TRY(ctx, hipMemsetAsync(&ws.counters[CNT_QUEUE], 0, sizeof(unsigned long long), stream)); // the item queue restarts
         bool timed = nseg < kMaxTimedSegments;
         if (timed && ctx->evp.size() < (size_t)kSegEvents * (nseg + 1u)) {
@@ -2622,7 +2638,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         if (h[CNT_PP0 + 7]) {
             const double tp = (double)h[CNT_PP0 + 7];
             fprintf(stderr, "[phase timing] pt_primary, share of its wave cycles: path start (Philox, jitter, lens, castRay) %.3f  list A %.3f  shade 0 (hit point, scatter) %.3f  "
-                            "list B %.3f  shade 1 %.3f  record write %.3f\n", h[CNT_PP0] / tp, h[CNT_PP0 + 1] / tp, h[CNT_PP0 + 2] / tp, h[CNT_PP0 + 3] / tp, h[CNT_PP0 + 4] / tp, h[CNT_PP0 + 5] / tp);
+                            "list B %.3f  shade 1 %.3f  record write %.3f  (of path start: index arithmetic %.3f)\n", h[CNT_PP0] / tp, h[CNT_PP0 + 1] / tp, h[CNT_PP0 + 2] / tp, h[CNT_PP0 + 3] / tp, h[CNT_PP0 + 4] / tp, h[CNT_PP0 + 5] / tp, h[CNT_PP0 + 6] / tp);
         }
         fprintf(stderr, "[phase timing]   within shade: hit point %.3f  scatter %.3f  miss (lerp + unwinding) %.3f;  within refill: path start %.3f\n",
                 h[16] / tot, h[17] / tot, h[18] / tot, h[19] / tot);
