@@ -123,3 +123,30 @@ def test_direct_and_rejection_frames_converge_to_one_image(gpu):
         assert abs(psnr[rps][0] - psnr[rps][1]) < 1.0, psnr   # direct vs rejection looks like rejection vs rejection
     assert psnr[1024][0] >= 40.0, psnr
     assert psnr[1024][0] - psnr[64][0] > 10.0, psnr             # 12 dB per 16x samples, within noise
+
+
+def test_direct_mode_converges_to_the_reference_sampler(orc, gpu):
+    """North star N4 in direct mode: the GPU's 4096-path frame drawn with PT_SAMPLER_DIRECT against the REFERENCE'S OWN sampler
+    (orc_render_sum_zig: main.zig:166-177's sequential std.rand streams and rejection loops): >= 40 dB at 1024 reference paths,
+    rising with the reference's sample count as two unbiased estimates of one image do."""
+    from path_tracer_amd import host
+    scene = host.Scene().setupScene(456, 21)
+    cam = host.Camera.preset(21)
+    gpu.set_scene(scene.spheres)
+    gpu.set_camera(cam.pod)
+    img = host.Image(48)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=1024, rebounds=50)
+    g = gpu.render_mean(host.make_pt_config(img, rt, seed=1, chunk=16, sampler=1)).astype(np.float64)
+    ocam = orc.Camera()
+    C.memmove(C.byref(ocam), C.byref(cam.pod), C.sizeof(ocam))
+    oimg = orc.image_new(48)
+    psnr = {}
+    for rps in (64, 256):
+        spheres, stream = orc.setup_scene(21, 456)
+        ocfg = orc.make_config(oimg, subpixels=4, rays_per_subsample=rps, rebounds=50, mode=2)
+        rc, s, st = orc.render_sum_zig(spheres, ocam, ocfg, stream)
+        assert rc == 0
+        z = orc.resolve_mean(ocfg, s).astype(np.float64)
+        psnr[4 * rps] = 10.0 * np.log10(1.0 / float(np.mean((g - z) ** 2)))
+    assert psnr[1024] >= 40.0, psnr
+    assert psnr[1024] >= psnr[256] + 3.0, psnr
