@@ -4,7 +4,7 @@ scene.zig:96-110 tests every sphere for every ray.  With PT_LIMIT_TREE_MIN_SPHER
 (conservative LDS filter + exact pass); with a tree it walks boxes and gives the exact Sphere.is_hit only to the spheres
 of the leaves it reaches.  Both must return the same closest hit for every ray — index and t, bit for bit — and so the
 same frames, path and ray counts.  PT_FN_SCENE_HIT is the plain ascending scan with strict '<' on the GPU (pinned
-against the oracle in test_gpu_functions.py); PT_FN_SCENE_HIT_TREE the tree walk on the same rays.
+against the oracle's scene_is_hit and the committed vectors in tests/test_golden.py and tests/test_analytic_kats.py); PT_FN_SCENE_HIT_TREE the tree walk on the same rays.
 """
 import numpy as np
 import pytest
