@@ -157,6 +157,8 @@ def lib():
         for name in ("orc_sample_disk", "orc_sample_ball"):
             getattr(L, name).argtypes = [C.c_uint32, fp, C.c_uint32, C.POINTER(C.c_uint32), fp]
             getattr(L, name).restype = None
+        L.orc_scene_hit_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        L.orc_scene_hit_batch.restype = None
         L.orc_sample_batch.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_sample_batch.restype = None
         _lib = L
@@ -254,6 +256,15 @@ def sample_batch(which, sampler, xi):
     xi = np.ascontiguousarray(xi, dtype=np.float32)
     out = np.zeros((xi.shape[0], 4), dtype=np.float32)
     lib().orc_sample_batch(0 if which == "disk" else 1, int(sampler), xi.ctypes.data, xi.shape[0], xi.shape[1], out.ctypes.data)
+    return out
+
+
+def scene_hit_batch(spheres, rays, t_min=0.1, t_max=1000.0):
+    """Scene.is_hit (scene.zig:96-110) for (n, 6) float32 rays -> (n, 8): index or -1, t, p, n — the record of PT_FN_SCENE_HIT."""
+    sp = np.ascontiguousarray(spheres)
+    r = np.ascontiguousarray(rays, dtype=np.float32)
+    out = np.zeros((r.shape[0], 8), dtype=np.float32)
+    lib().orc_scene_hit_batch(sp.ctypes.data, len(sp), r.ctypes.data, r.shape[0], float(t_min), float(t_max), out.ctypes.data)
     return out
 
 

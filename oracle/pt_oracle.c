@@ -967,6 +967,16 @@ void orc_sample_batch(int which, uint32_t sampler, const float *xi, uint32_t n, 
         out4[4 * (size_t)i + 3] = (float)used;
     }
 }
+/* n rays (o, d: 6 floats each) -> (index or -1, t, p, n: 8 floats each): scene.zig:96-110 ray by ray */
+void orc_scene_hit_batch(const orc_sphere *sp, uint32_t n_sp, const float *rays, uint32_t n, float t_min, float t_max, float *out8) {
+    for (uint32_t i = 0; i < n; i++) {
+        float t = 0.0f, p[3] = {0, 0, 0}, nn[3] = {0, 0, 0};
+        const int idx = orc_scene_hit(sp, n_sp, rays + 6 * (size_t)i, rays + 6 * (size_t)i + 3, t_min, t_max, &t, p, nn);
+        float *w = out8 + 8 * (size_t)i;
+        w[0] = (float)idx; w[1] = idx >= 0 ? t : 0.0f;
+        for (int k = 0; k < 3; k++) { w[2 + k] = idx >= 0 ? p[k] : 0.0f; w[5 + k] = idx >= 0 ? nn[k] : 0.0f; }
+    }
+}
 void orc_reflect(const float d[3], const float n[3], float out[3]) {
     vec3 r = reflect(v3(d[0], d[1], d[2]), v3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }

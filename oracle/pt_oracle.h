@@ -135,6 +135,7 @@ int orc_scene_hit(const orc_sphere *sp, uint32_t n, const float o[3], const floa
 void orc_sample_disk(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]); /* camera.zig:113-120 / direct */
 void orc_sample_ball(uint32_t sampler, const float *xi, uint32_t n_xi, uint32_t *n_used, float out[3]); /* material.zig:27-34 / direct */
 void orc_sample_batch(int which /* 0 disk, 1 ball */, uint32_t sampler, const float *xi, uint32_t n, uint32_t stride, float *out4 /* p, n_used */);
+void orc_scene_hit_batch(const orc_sphere *sp, uint32_t n_sp, const float *rays, uint32_t n, float t_min, float t_max, float *out8); /* scene.zig:96-110 on n rays */
 void orc_reflect(const float d[3], const float n[3], float out[3]);          /* material.zig:59-65 */
 int orc_refract(const float d[3], const float n[3], float n1_over_n2, float out[3]); /* material.zig:98-116; 0 = null */
 float orc_schlick(float cosine, float refraction_index);                     /* material.zig:120-124 */

@@ -201,6 +201,32 @@ def test_tree_frame_against_the_oracle(orc, gpu):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_tree_walk_against_the_oracle_ray_by_ray(orc, gpu):
+    """The tree walk tied to the ORACLE directly (not to the GPU's own scan): Scene.is_hit of scene.zig:96-110 as the C restatement runs
+    it, ray by ray, on the adversarial rays of this file — scene 21 (tree in LDS), a 3 000-sphere scene (tree in global memory) and a
+    scene of huge, tiny, negative, coincident and concentric spheres; index, t, hit point and normal, bit for bit; t_min 0.1, 0 and < 0."""
+    from path_tracer_amd import _lib, host
+    rng = np.random.default_rng(77)
+    odd = np.zeros(700, dtype=_lib.SPHERE_DTYPE)
+    c = np.round(rng.normal(0, 4, (700, 3)))                       # a lattice: many coincident and concentric centres
+    odd["cx"], odd["cy"], odd["cz"] = c[:, 0], c[:, 1], c[:, 2]
+    odd["radius"] = rng.choice([1e-3, 0.02, 0.3, 0.5, 2.0, 60.0, -0.7], 700)
+    scenes = [host.Scene().setupScene(456, 21).spheres, host.Scene().sceneSynthetic(3000, 1).spheres, odd]
+    total_hits = 0
+    for sp in scenes:
+        gpu.set_scene(sp)
+        assert gpu.tree_info()["nodes"] > 0
+        rays = _rays(rng, sp, 40_000)
+        for t_min in (0.1, 0.0, -1.0):
+            got = gpu.debug_eval(_lib.PT_FN_SCENE_HIT_TREE, rays, t_min=t_min, t_max=1000.0)
+            want = orc.scene_hit_batch(sp, rays, t_min=t_min, t_max=1000.0)
+            np.testing.assert_array_equal(got[:, 0], want[:, 0])
+            hit = want[:, 0] >= 0
+            np.testing.assert_array_equal(got[hit].view(np.uint32), want[hit].view(np.uint32))
+            total_hits += int(hit.sum())
+    assert total_hits > 100_000
+
+
 def test_lists_built_by_the_tree_walk_random_cameras_and_adversarial_scenes(gpu):
     """The primary pass of a tree scene builds its per-pixel lists by walking the tree (pt_primary_lists<true>): frames with
     those lists + the tree megakernel against frames without the primary pass through the scan, over pinhole to very wide
