@@ -96,6 +96,10 @@ pub const PT_LIMIT_PRIMARY_BYTES: c_int = 1;
 pub const PT_LIMIT_PRIMARY_BOUNCES: c_int = 2; // 1: camera rays only, 2 (default): also the rays scattered off each pixel's main diffuse sphere
 pub const PT_LIMIT_TREE_MIN_SPHERES: c_int = 3; // scenes of at least this many spheres (default 256; 0: never) are traced through a sphere tree; set before ptgpu_set_scene
 pub extern fn ptgpu_set_limit(ctx: *PtCtx, which: c_int, value: u64) c_int;
+pub extern fn ptgpu_trim(ctx: *PtCtx) c_int; // frees every work buffer the renders have grown (records, partials, stack); the scene stays
+pub extern fn ptgpu_work_bytes(ctx: *const PtCtx) u64;
+pub const PT_SAMPLER_REJECTION: u32 = 0; // the reference's rejection loops (camera.zig:113-120, material.zig:27-34)
+pub const PT_SAMPLER_DIRECT: u32 = 1; // the same distributions without a loop (not in the reference)
 pub extern fn ptgpu_tree_info(ctx: *const PtCtx, nodes: ?*u32, depth: ?*u32) c_int;
 pub extern fn ptgpu_debug_tree_check(spheres: [*]const PtSphere, n: u32, median_only: c_int, nodes: ?*u32, depth: ?*u32, leaves: ?*u32, violations: *u64) c_int; // host-only builder self-check
 pub extern fn ptgpu_strerror(status: c_int) [*:0]const u8;
@@ -234,7 +238,7 @@ pub fn renderMultiGpu(cfg: RendererConfig, seed: u64, num_gpus: c_int, split: c_
 test "extern struct sizes match include/ptgpu.h" {
     try std.testing.expectEqual(@as(usize, 36), @sizeOf(PtSphere));
     try std.testing.expectEqual(@as(usize, 76), @sizeOf(PtCamera));
-    try std.testing.expectEqual(@as(usize, 104), @sizeOf(PtConfig));
+    try std.testing.expectEqual(@as(usize, 112), @sizeOf(PtConfig)); // ABI 3: sampler, reserved_
     try std.testing.expectEqual(@as(usize, 24), @offsetOf(PtConfig, "seed"));
     try std.testing.expectEqual(@as(usize, 88), @offsetOf(PtConfig, "tile_pixels"));
 }
