@@ -62,8 +62,10 @@ constexpr uint32_t kItemBatch = 64;  // work items a wave reserves per queue ato
 #define PT_SUB 4
 #endif
 #ifndef PT_REFILL_ROUNDS
-#define PT_REFILL_ROUNDS 2 // with primary-pass records: refill rounds per ray step while some lane used its item up (rows of sky are all such
-                           // items).  Measured on the headline frame, 2 / 4 / 16 rounds: lane utilisation 0.966 / 0.983 / 0.993 but 175.1 / 175.2 / 179.3 ms
+#define PT_REFILL_ROUNDS 1 // with primary-pass records: refill rounds per ray step while some lane used its item up (rows of sky are all such
+                           // items).  Round 2, headline frame, 2 / 4 / 16 rounds: lane utilisation 0.966 / 0.983 / 0.993 but 175.1 / 175.2 / 179.3 ms.
+                           // Round 3 (tree walk, shorter steps), per 256 samples, 1 / 2 / 3 rounds: 33.9 / 34.35 / 34.6 ms — the second round's code is
+                           // run by every wave step whether or not a lane needs it; one round
 #endif
 #ifndef PT_WORDS_PER_ITER
 #define PT_WORDS_PER_ITER 4 // mask words (x32 tests) per unrolled scan-loop iteration; measured 1/2/4/8: 432.3/429.8/428.6/433.0 ms
