@@ -232,7 +232,8 @@ def main():
         list_rays_l = prim_rays_l + list2_l
         mk_rays = rays_l - list_rays_l                                    # rays the megakernel traces
         cands_l, pcands_l, boxes_l = cands / K, prim_cands / K, boxes / K
-        counters = load_counters(args.spp) if headline else None
+        shipped = args.tree_min_spheres is None and args.primary_bytes is None   # (A/B switches select other kernels than the ones profiled)
+        counters = load_counters(args.spp) if (headline and shipped) else None
         ck = (counters or {}).get("kernels", {})
 
         def peak_frac(flops, ms):
