@@ -12,7 +12,7 @@ mkdir -p $out
 BENCH_ARGS=("$@")
 pass() { # name, counters...
   local name=$1; shift
-  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o p -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "${BENCH_ARGS[@]}" > $out/$name.json 2> $out/$name.err || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o p -- python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 0 "${BENCH_ARGS[@]}" > $out/$name.json 2> $out/$name.err || exit 1
 }
 pass pmc_valu SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY
 pass pmc_lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM
