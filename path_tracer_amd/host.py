@@ -218,14 +218,14 @@ def make_pt_config(img, rt, seed=0, istart=0, istop=None, deterministic=False, s
     return c
 
 
-def render(gpu, scene, camera, img, ray_tracer_config, seed, slice_, istart=0, istop=None, deterministic=False, chunk=0):
+def render(gpu, scene, camera, img, ray_tracer_config, seed, slice_, istart=0, istop=None, deterministic=False, chunk=0, sampler=0):
     """render(cfg) of renderers/ppm_image.zig:30-87 on one GPU: writes the pixel records of
     [istart, istop) into `slice_` (uint8 array of img.size bytes).  The caller writes the
     header afterwards (main.zig:180-182)."""
     assert isinstance(gpu, GpuContext)
     gpu.set_scene(scene.spheres)
     gpu.set_camera(camera.pod)
-    cfg = make_pt_config(img, ray_tracer_config, seed, istart, istop, deterministic, chunk=chunk)
+    cfg = make_pt_config(img, ray_tracer_config, seed, istart, istop, deterministic, chunk=chunk, sampler=sampler)
     gpu.render_ppm(cfg, slice_, img.header_size, img.px_size)
     return cfg
 

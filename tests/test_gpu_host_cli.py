@@ -11,11 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "path_tracer_amd", "pt_render")
 
 
-def _oracle_file(orc, n_scene, width, spp, depth, seed, deterministic):
+def _oracle_file(orc, n_scene, width, spp, depth, seed, deterministic, sampler=0):
     spheres, _ = orc.setup_scene(n_scene, seed)
     cam = orc.camera_preset(n_scene)
     img = orc.image_new(width)
-    cfg = orc.make_config(img, subpixels=4, rays_per_subsample=spp, rebounds=depth, seed=seed, mode=1 if deterministic else 0)
+    cfg = orc.make_config(img, subpixels=4, rays_per_subsample=spp, rebounds=depth, seed=seed, mode=1 if deterministic else 0, sampler=sampler)
     rc, ref_sum, _ = orc.render_sum(spheres, cam, cfg, nthreads=8)
     rc2, ppm = orc.resolve_ppm(cfg, img, ref_sum)
     assert rc == 0 and rc2 == 0
@@ -35,6 +35,19 @@ def test_pt_render_cli_writes_the_oracle_file(orc, tmp_path, n_scene, width, spp
     assert r.returncode == 0, r.stderr
     assert "paths/s" in r.stderr and "Program took" in r.stderr          # main.zig:191's log line
     assert out.read_bytes() == _oracle_file(orc, n_scene, width, spp, depth, seed, det)
+
+
+def test_pt_render_cli_direct_sampler(orc, tmp_path):
+    """--sampler direct: pt_config.sampler = PT_SAMPLER_DIRECT through the C++ host; the file is the oracle's in that mode, and differs
+    from the default mode's."""
+    out, ref = tmp_path / "direct.ppm", tmp_path / "rejection.ppm"
+    base = [EXE, "--scene", "21", "--width", "64", "--spp", "3", "--depth", "50", "--seed", "456"]
+    r = subprocess.run(base + ["--sampler", "direct", "--out", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == _oracle_file(orc, 21, 64, 3, 50, 456, False, sampler=orc.SAMPLER_DIRECT)
+    r = subprocess.run(base + ["--sampler", "rejection", "--out", str(ref)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ref.read_bytes() == _oracle_file(orc, 21, 64, 3, 50, 456, False) and ref.read_bytes() != out.read_bytes()
+    assert subprocess.run(base + ["--sampler", "sobol"], capture_output=True, timeout=60).returncode == 2
 
 
 def test_pt_render_cli_default_file_name_and_bad_scene(tmp_path):
