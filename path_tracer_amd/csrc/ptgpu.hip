@@ -2467,9 +2467,14 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
     if (prim_cap == kPrimaryAuto) {
         // Sized from what the device has free NOW (plus what this context already holds for the pass): half of it, so that a
         // host sharing the GPU with other allocators keeps room; the buffer is then allocated at the size the render needs.
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-        prim_cap = std::min<uint64_t>(kPrimaryAutoMax, ((uint64_t)free_b + (uint64_t)ctx->prim_bytes) / 2u);
+        // A context that already holds enough for the whole frame (a render loop's second and later calls) asks nothing.
+        const uint64_t whole = (uint64_t)npix * prim_per_slot + 2048u;
+        if (ctx->d_prim && (uint64_t)ctx->prim_bytes >= whole) prim_cap = std::min<uint64_t>(kPrimaryAutoMax, (uint64_t)ctx->prim_bytes);
+        else {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+            prim_cap = std::min<uint64_t>(kPrimaryAutoMax, ((uint64_t)free_b + (uint64_t)ctx->prim_bytes) / 2u);
+        }
     }
     const uint64_t part_fit = fit_slots(part_avail, part_per_slot);
     if (part_fit < 64) return noalloc ? PT_ERR_SCRATCH_LIMIT : PT_ERR_BAD_ARG; // not even one wave of slots: raise the limit / chunk
