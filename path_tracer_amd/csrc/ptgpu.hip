@@ -404,7 +404,11 @@ __device__ __forceinline__ void scene_is_hit_filtered(const float4 *g_filt, cons
 // kTreeKappa = 8e-3 >= sqrt(g) (sqrt 6 + 1) = 6.9e-3 >= (r' - r) / m; the rest covers the slab arithmetic
 // (every term is a difference to o, so its rounding is relative to m as well).  A ray on the boundary of
 // a grown box (0 x inf = NaN in a slab) may go either way: it is >= mu away from every sphere in it.
-struct TreeNode { float4 a, b, c; uint4 ch; }; // boxes of the two children: a = (lo0, hi0.x), b = (hi0.yz, lo1.xy), c = (lo1.z, hi1); ch.x, ch.y = child refs
+// Boxes are stored as centre bc and half extents bh (bc - bh <= lo, hi <= bc + bh in exact arithmetic: the builder rounds bh up), and the
+// test uses m = max_axis |bc - o| + max_axis bh, which is >= the m above (|lo - o|, |hi - o| <= |bc - o| + bh per axis), so the same
+// argument holds with a slightly larger margin.  Per axis the ray is inside the grown slab for |t - tc| <= (bh + mu) |1/d|, tc = (bc - o) / d:
+// 24 VALU instructions per box against 37 for the corner form (three subtractions instead of six, no separate growth of each corner).
+struct TreeNode { float4 a, b, c; uint4 ch; }; // boxes of the two children: a = (bc0, bh0.x), b = (bh0.yz, bc1.xy), c = (bc1.z, bh1); ch.x, ch.y = child refs
 #ifndef PT_TREE_LEAF
 #define PT_TREE_LEAF 4 // measured 1 / 2 / 4: 280.3 / 259.3 / 253.7 ms per frame of the 100 000-sphere scene, 36.8 / 37.0 / 38.6 ms per 256 samples of 3 000 spheres
 #endif
@@ -414,16 +418,18 @@ constexpr uint32_t kTreeStack = 24;        // stack entries per lane = deepest t
 constexpr uint32_t kTreeLeafBit = 0x80000000u, kTreeNone = 0xffffffffu; // leaf ref: bit 31 | (count - 1) << 28 | first slot of the leaf arrays
 constexpr float kTreeKappa = 8e-3f;
 
-__device__ __forceinline__ bool tree_box(V3 o, V3 inv, float lox, float loy, float loz, float hix, float hiy, float hiz, float t_lo, float t_hi,
+__device__ __forceinline__ bool tree_box(V3 o, V3 inv, float bcx, float bcy, float bcz, float bhx, float bhy, float bhz, float t_lo, float t_hi,
                                          float &t_near) {
-    const float lx = lox - o.x, hx = hix - o.x, ly = loy - o.y, hy = hiy - o.y, lz = loz - o.z, hz = hiz - o.z;
-    const float m = fmaxf(fmaxf(fmaxf(fabsf(lx), fabsf(hx)), fmaxf(fabsf(ly), fabsf(hy))), fmaxf(fabsf(lz), fabsf(hz)));
+    const float dx = bcx - o.x, dy = bcy - o.y, dz = bcz - o.z;
+    const float m = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) + fmaxf(fmaxf(bhx, bhy), bhz);
     const float mu = kTreeKappa * m;
-    const float t1x = (lx - mu) * inv.x, t2x = (hx + mu) * inv.x;
-    const float t1y = (ly - mu) * inv.y, t2y = (hy + mu) * inv.y;
-    const float t1z = (lz - mu) * inv.z, t2z = (hz + mu) * inv.z;
-    t_near = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), t_lo));
-    const float t_far = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), t_hi));
+    const float tcx = dx * inv.x, tcy = dy * inv.y, tcz = dz * inv.z;
+    const float gx = bhx + mu, gy = bhy + mu, gz = bhz + mu;
+    const float ax = fabsf(inv.x), ay = fabsf(inv.y), az = fabsf(inv.z);
+    // (a zero direction component: tc = +-inf or NaN, the products inf — each bound is then +-inf on the open side or NaN, and min / max
+    // drop NaN operands: the axis constrains nothing, which errs on the side of entering the box)
+    t_near = fmaxf(fmaxf(fmaf(-gx, ax, tcx), fmaf(-gy, ay, tcy)), fmaxf(fmaf(-gz, az, tcz), t_lo));
+    const float t_far = fminf(fminf(fmaf(gx, ax, tcx), fmaf(gy, ay, tcy)), fminf(fmaf(gz, az, tcz), t_hi));
     return t_near <= t_far;
 }
 
@@ -488,7 +494,9 @@ static __device__ unsigned long long g_walk_prof[8];
 #endif
 template <class Tree>
 __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t &pend, uint32_t exit_at, uint32_t flush_at, uint32_t tid, V3 o, V3 d, float a,
-                                                  float t_min, float t_max, float &closest, int &hit, uint32_t &n_cands, uint32_t &n_iters, uint32_t &n_boxes) {
+                                                  float t_min, float t_max, float &closest, int &hit, unsigned long long &w_cands, uint32_t &n_iters, unsigned long long &w_boxes) {
+    // w_cands, n_iters, w_boxes: counts of the WAVE (sums of popcounts: scalar instructions; per-lane counters cost three VALU
+    // additions and their loop-carried copies in every iteration of a loop that is bound by VALU issue)
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     // (a lane without a ray stays out — the caller gives it cur = kNone: its parked NaN direction would pass every box, min/max drop NaN operands)
@@ -522,6 +530,13 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
         }
 #endif
         if ((uint32_t)__popcll(m_pend) >= flush_at || m_inner == 0ull) { // wave-uniform
+            {   // (counted here, where control flow is still uniform — inside the lanes' branch the sum would be a per-lane value again —
+                // as one popcount per bit of the leaves' count field: sum of counts = lanes + sum_b 2^b lanes with bit b of (count - 1))
+                const uint32_t cm1 = pend != Tree::kNone ? Tree::count(pend) - 1u : 0u;
+                w_cands += (unsigned long long)__popcll(m_pend);
+#pragma unroll
+                for (uint32_t b = 0; (1u << b) < kTreeLeaf; ++b) w_cands += (unsigned long long)__popcll(__ballot((cm1 >> b) & 1u)) << b;
+            }
             if (pend != Tree::kNone) {
                 const uint32_t first = Tree::first(pend), cnt = Tree::count(pend);
 #pragma unroll
@@ -529,7 +544,6 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
                     if (k < cnt) {
                         float4 g; uint32_t id;
                         T.sphere(first + k, g, id);
-                        n_cands++;
                         float t;
                         if (sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) {
                             // the scan's outcome: smallest t, and among equal t the lowest sphere index
@@ -540,11 +554,11 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
                 pend = Tree::kNone;
             }
         }
+        w_boxes += 2ull * (unsigned long long)__popcll(m_inner);
         if (at_inner) {
             float4 A, B, C; uint32_t c0, c1;
             T.node(cur, A, B, C, c0, c1);
             float n0, n1;
-            n_boxes += 2u;
             const bool h0 = tree_box(o, inv, A.x, A.y, A.z, A.w, B.x, B.y, t_min, closest, n0);
             const bool h1 = tree_box(o, inv, B.z, B.w, C.x, C.y, C.z, C.w, t_min, closest, n1);
             if (h0 && h1) {
@@ -653,8 +667,10 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
     int t_hit = -1;
     typename std::conditional<DET, ConstRng, PhiloxRng>::type rng;
     rng.init(P.seed_lo, P.seed_hi);
-    uint32_t n_rays = 0, n_cands = 0, n_paths = 0, n_not_unit = 0, n_boxes = 0; // per-lane counts (widened when the wave sums them)
+    uint32_t n_cands = 0, n_paths = 0, n_not_unit = 0; // per-lane counts (widened when the wave sums them)
+    unsigned long long w_rays_traced = 0;             // wave-uniform
     uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
+    unsigned long long w_tree_cands = 0, w_tree_boxes = 0;  // wave-uniform: exact tests and box tests of the tree walk
     unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
     unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
@@ -819,16 +835,16 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
             }
             if (TREE_LDS)
                 scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max,
-                                  t_closest, t_hit, n_cands, n_flush_iters, n_boxes);
+                                  t_closest, t_hit, w_tree_cands, n_flush_iters, w_tree_boxes);
             else
                 scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
-                                  t_hit, n_cands, n_flush_iters, n_boxes);
+                                  t_hit, w_tree_cands, n_flush_iters, w_tree_boxes);
             tracing = tracing && t_cur == kNone && t_sp == 0u && t_pend == kNone; // lanes still walking skip this step's shading and keep their ray
             closest = t_closest; hit = t_hit;
         } else
             scene_is_hit_filtered<MULTI_TILE>(P.filt, P.ycy, P.has_shared != 0u, s_ycy, n_pad, s_filt, s_mask, tid, geom_of, o, d, a, P.t_min, P.t_max, closest, hit,
                                               n_cands, n_flush_iters, t_flush);
-        if (tracing) n_rays++;
+        w_rays_traced += (unsigned long long)__popcll(__ballot(tracing));
         n_wave_steps++;
         PT_STAMP(tC0);
         PT_ACC(1, tB0, tC0);
@@ -911,8 +927,8 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
     }
 #endif
     // ---- statistics ---------------------------------------------------------------
-    const unsigned long long w_rays = wave_sum_u64(n_rays), w_cands = wave_sum_u64(n_cands), w_paths = wave_sum_u64(n_paths),
-                             w_not_unit = wave_sum_u64(n_not_unit), w_boxes = TREE ? wave_sum_u64(n_boxes) : 0ull;
+    const unsigned long long w_rays = w_rays_traced, w_cands = TREE ? w_tree_cands : wave_sum_u64(n_cands),
+                             w_paths = wave_sum_u64(n_paths), w_not_unit = wave_sum_u64(n_not_unit), w_boxes = w_tree_boxes;
     if (lane == 0) {
         atomicAdd(&P.counters[CNT_RAYS], w_rays);
         atomicAdd(&P.counters[CNT_CANDS], w_cands);
@@ -993,7 +1009,7 @@ __global__ __launch_bounds__(256) void pt_list_prep(const ListCam C, const float
     out[j] = S;
 }
 
-// One lane's walk of the sphere tree for the list kernel: box_ok(lo, hi) says whether a box can hold a sphere the
+// One lane's walk of the sphere tree for the list kernel: box_ok(bc, bh) says whether a box (centre, half extents) can hold a sphere the
 // list wants, leaf(slot) looks at the sphere in leaf slot `slot` and returns false to end the walk (the list has
 // overflowed).  (Lanes walk independently: no wave-level operation inside; neighbouring pixels take nearly the same way.)
 template <class BoxOk, class Leaf>
@@ -1063,18 +1079,17 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
     const float inv_lenD = lenD > 0.0f ? (1.0f + 1e-5f) / lenD : 0.0f;
     const float a1f = (float)a1 * (1.0f + 1e-6f), b2f = (float)b2 * (1.0f + 1e-6f);
     uint32_t count = 0;
-    // the ball around a box, relative to the camera: x = bc - O, |x|^2, radius hd (rounded up)
-    auto box_ball = [&](float lx, float ly, float lz, float hx, float hy, float hz, double x[3], double &xx, double &hd) {
-        x[0] = 0.5 * ((double)lx + (double)hx) - C.O[0]; x[1] = 0.5 * ((double)ly + (double)hy) - C.O[1]; x[2] = 0.5 * ((double)lz + (double)hz) - C.O[2];
+    // the ball around a box (centre bc, half extents bh), relative to the camera: x = bc - O, |x|^2, radius hd (rounded up)
+    auto box_ball = [&](float cx, float cy, float cz, float hx, float hy, float hz, double x[3], double &xx, double &hd) {
+        x[0] = (double)cx - C.O[0]; x[1] = (double)cy - C.O[1]; x[2] = (double)cz - C.O[2];
         xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-        const double ex = (double)hx - (double)lx, ey = (double)hy - (double)ly, ez = (double)hz - (double)lz;
-        hd = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * (1.0 + 1e-12);
+        hd = sqrt((double)hx * hx + (double)hy * hy + (double)hz * hz) * (1.0 + 1e-12);
     };
     if (TREE) {
         list_tree_walk(tnodes, troot, s_stack, threadIdx.x, act,
-            [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+            [&](float cx, float cy, float cz, float hx, float hy, float hz) -> bool {
                 double x[3], xx, hd;
-                box_ball(lx, ly, lz, hx, hy, hz, x, xx, hd);
+                box_ball(cx, cy, cz, hx, hy, hz, x, xx, hd);
                 const double xl = sqrt(xx) + hd + C.Rl;                                // >= |c - O| + Rl of every sphere inside
                 double R = hd + sqrt(kListGamma * (2.0 * xl * xl + hd * hd)) * (1.0 + 1e-9); // >= hd - r + r' of each of them (pt_list_prep's r')
                 // list_piece lets a sphere in that is outside by up to its tolerance (1e-9 relative in squared distance, < 1e-4 (|x| + R)
@@ -1288,9 +1303,9 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
         // above may add to a sphere's radius (1e-5 relative + err), so that a sphere that test lets in always finds its boxes open
         const double cosAd = (double)cosAf, sinAd = (double)sinAf;
         list_tree_walk(tnodes, troot, s_stack, threadIdx.x, doB,
-            [&](float lx, float ly, float lz, float hx, float hy, float hz) -> bool {
+            [&](float cx, float cy, float cz, float hx, float hy, float hz) -> bool {
                 double x[3], xx, hd;
-                box_ball(lx, ly, lz, hx, hy, hz, x, xx, hd);
+                box_ball(cx, cy, cz, hx, hy, hz, x, xx, hd);
                 double y[3], yy = 0.0, ya = 0.0;
                 for (int i = 0; i < 3; ++i) { y[i] = x[i] - tau0 * Dv[i]; yy += y[i] * y[i]; ya += y[i] * ax[i]; }
                 const double yl = sqrt(yy), ylu = yl + hd + rho_p;
@@ -1776,8 +1791,8 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     const float a = vlen2(d);
     float closest = t_max;
     int hit = -1;
-    uint32_t n_cands = 0, n_iters = 0;
-    uint32_t sp = 0, n_boxes = 0;
+    unsigned long long n_cands = 0, n_boxes = 0;
+    uint32_t sp = 0, n_iters = 0;
     if (LDS) {
         uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone, pend = TreeInLds::kNone;
         scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, pend, 0u, flush_at, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
@@ -2066,6 +2081,7 @@ struct TreeBuild {
     std::vector<float4> tgeom;
     std::vector<uint32_t> tprim;
     uint32_t root = 0, depth = 0;
+    bool finite = true; // every stored box has finite centre and half extents
     bool sah = true; // false: median splits only (at most n / 2 leaves, ceil(log2(n / kTreeLeaf)) + 1 levels)
 };
 struct TreeBox {
@@ -2075,6 +2091,19 @@ struct TreeBox {
     double area() const {
         const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
         return (x < 0.0) ? 0.0 : x * y + y * z + z * x;
+    }
+    // the box as the walk stores it: centre bc and half extents bh with bc - bh <= lo and hi <= bc + bh in exact arithmetic (bh rounded up);
+    // false when a coordinate is not finite (centre +- radius overflowed: such a scene keeps the scan)
+    bool centre_form(float bc[3], float bh[3]) const {
+        for (int k = 0; k < 3; ++k) {
+            bc[k] = (float)(0.5 * ((double)lo[k] + (double)hi[k]));
+            const double h = std::max((double)hi[k] - (double)bc[k], (double)bc[k] - (double)lo[k]); // exact in double
+            float hf = (float)h;
+            if ((double)hf < h) hf = nextafterf(hf, INFINITY);
+            bh[k] = hf;
+            if (!std::isfinite(bc[k]) || !std::isfinite(bh[k])) return false;
+        }
+        return true;
     }
 };
 static TreeBox tree_sphere_box(const pt_sphere &s) {
@@ -2148,9 +2177,11 @@ static uint32_t tree_build_range(const pt_sphere *sp, std::vector<uint32_t> &idx
     const uint32_t c0 = tree_build_range(sp, idx, b, mid, level + 1u, T, b0);
     const uint32_t c1 = tree_build_range(sp, idx, mid, e, level + 1u, T, b1);
     TreeNode &N = T.nodes[me];
-    N.a = make_float4(b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]);
-    N.b = make_float4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
-    N.c = make_float4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
+    float bc0[3], bh0[3], bc1[3], bh1[3];
+    if (!b0.centre_form(bc0, bh0) || !b1.centre_form(bc1, bh1)) T.finite = false;
+    N.a = make_float4(bc0[0], bc0[1], bc0[2], bh0[0]);
+    N.b = make_float4(bh0[1], bh0[2], bc1[0], bc1[1]);
+    N.c = make_float4(bc1[2], bh1[0], bh1[1], bh1[2]);
     N.ch = make_uint4(c0, c1, 0u, 0u);
     box.add(b0); box.add(b1);
     return me;
@@ -2165,7 +2196,7 @@ static bool tree_build(const pt_sphere *sp, uint32_t n, TreeBuild &T) {
     TreeBox box;
     T.root = tree_build_range(sp, idx, 0u, n, 1u, T, box);
     if (T.nodes.empty()) T.nodes.emplace_back(); // a one-leaf scene: the root ref is the leaf, the node array is never read
-    return T.depth <= kTreeStack;
+    return T.depth <= kTreeStack && T.finite;
 }
 
 // Host-only check of the builder (no device needed; tests/test_host.py): builds the tree ptgpu_set_scene would build and
@@ -2180,10 +2211,13 @@ extern "C" int ptgpu_debug_tree_check(const pt_sphere *spheres, uint32_t n, int 
     uint64_t bad = 0;
     uint32_t n_leaves = 0;
     std::vector<uint8_t> seen(n, 0);
-    struct Item { uint32_t ref; TreeBox box; bool has_box; };
+    // every stored box (bc -+ bh, taken exactly, in double) with a link to its parent's: stored boxes need not nest (each is rounded on
+    // its own), so a sphere is checked against the box of EVERY ancestor — a walk skips a subtree on any one of them
+    struct CheckBox { double lo[3], hi[3]; int parent; };
+    std::vector<CheckBox> boxes;
+    struct Item { uint32_t ref; int box; };
     std::vector<Item> todo;
-    todo.push_back(Item{T.root, TreeBox(), false});
-    std::vector<TreeBox> chain; // (boxes are nested by construction only if every child box lies in its parent's: checked via the spheres)
+    todo.push_back(Item{T.root, -1});
     while (!todo.empty()) {
         const Item it = todo.back();
         todo.pop_back();
@@ -2198,23 +2232,27 @@ extern "C" int ptgpu_debug_tree_check(const pt_sphere *spheres, uint32_t n, int 
                 const pt_sphere &s = spheres[id];
                 const float4 g = T.tgeom[first + k];
                 if (memcmp(&g.x, &s.cx, 4) || memcmp(&g.y, &s.cy, 4) || memcmp(&g.z, &s.cz, 4) || memcmp(&g.w, &s.radius, 4)) bad++;
-                if (it.has_box) {
-                    const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
+                const float c[3] = {s.cx, s.cy, s.cz}, r = fabsf(s.radius);
+                for (int bx = it.box; bx >= 0; bx = boxes[bx].parent) {
+                    bool out = false;
                     for (int a = 0; a < 3; ++a)
-                        if (!((double)it.box.lo[a] <= (double)c[a] - r && (double)c[a] + r <= (double)it.box.hi[a])) { bad++; break; }
+                        if (!(boxes[bx].lo[a] <= (double)c[a] - r && (double)c[a] + r <= boxes[bx].hi[a])) out = true;
+                    if (out) { bad++; break; }
                 }
             }
         } else {
             if (it.ref >= T.nodes.size()) { bad++; continue; }
             const TreeNode &N = T.nodes[it.ref];
-            TreeBox b0, b1;
-            b0.lo[0] = N.a.x; b0.lo[1] = N.a.y; b0.lo[2] = N.a.z; b0.hi[0] = N.a.w; b0.hi[1] = N.b.x; b0.hi[2] = N.b.y;
-            b1.lo[0] = N.b.z; b1.lo[1] = N.b.w; b1.lo[2] = N.c.x; b1.hi[0] = N.c.y; b1.hi[1] = N.c.z; b1.hi[2] = N.c.w;
-            if (it.has_box) // a child's box inside its parent's: then "inside the leaf's box" above means inside every ancestor's
-                for (int a = 0; a < 3; ++a)
-                    if (b0.lo[a] < it.box.lo[a] || b1.lo[a] < it.box.lo[a] || b0.hi[a] > it.box.hi[a] || b1.hi[a] > it.box.hi[a]) { bad++; break; }
-            todo.push_back(Item{N.ch.x, b0, true});
-            todo.push_back(Item{N.ch.y, b1, true});
+            CheckBox b0, b1;
+            const float bc0[3] = {N.a.x, N.a.y, N.a.z}, bh0[3] = {N.a.w, N.b.x, N.b.y}, bc1[3] = {N.b.z, N.b.w, N.c.x}, bh1[3] = {N.c.y, N.c.z, N.c.w};
+            for (int a = 0; a < 3; ++a) {
+                b0.lo[a] = (double)bc0[a] - bh0[a]; b0.hi[a] = (double)bc0[a] + bh0[a];
+                b1.lo[a] = (double)bc1[a] - bh1[a]; b1.hi[a] = (double)bc1[a] + bh1[a];
+                if (!(bh0[a] >= 0.0f) || !(bh1[a] >= 0.0f) || !std::isfinite(bc0[a]) || !std::isfinite(bc1[a]) || !std::isfinite(bh0[a]) || !std::isfinite(bh1[a])) bad++;
+            }
+            b0.parent = b1.parent = it.box;
+            boxes.push_back(b0); todo.push_back(Item{N.ch.x, (int)boxes.size() - 1});
+            boxes.push_back(b1); todo.push_back(Item{N.ch.y, (int)boxes.size() - 1});
         }
     }
     for (uint32_t i = 0; i < n; ++i) if (!seen[i]) bad++;
