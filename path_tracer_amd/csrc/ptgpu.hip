@@ -494,8 +494,8 @@ static __device__ unsigned long long g_walk_prof[8];
 #endif
 template <class Tree>
 __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, uint32_t &sp, uint32_t &pend, uint32_t exit_at, uint32_t flush_at, uint32_t tid, V3 o, V3 d, float a,
-                                                  float t_min, float t_max, float &closest, int &hit, unsigned long long &w_cands, uint32_t &n_iters, unsigned long long &w_boxes) {
-    // w_cands, n_iters, w_boxes: counts of the WAVE (sums of popcounts: scalar instructions; per-lane counters cost three VALU
+                                                  float t_min, float t_max, float &closest, int &hit, unsigned long long &w_cands, unsigned long long &w_iters, unsigned long long &w_boxes) {
+    // w_cands, w_iters, w_boxes: counts of the WAVE (sums of popcounts: scalar instructions; per-lane counters cost three VALU
     // additions and their loop-carried copies in every iteration of a loop that is bound by VALU issue)
     // 1/d to within an ulp or two is enough (kTreeKappa's reserve); a zero component gives inf: the slab is then all of t or none of it
     const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
@@ -520,7 +520,7 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
         const unsigned long long walking = m_pend | __ballot(cur != Tree::kNone);
         if (walking == 0ull) break;
         if (exit_at != 0u && walking != walking0 && (uint32_t)__popcll(walking) <= exit_at) break;
-        n_iters++;
+        w_iters += (unsigned long long)__popcll(walking & (0ull - walking)); // + 1 (the lowest walking lane), in a form that stays a scalar popcount: as `n++` the compiler keeps this wave-uniform count in a VGPR, two VALU instructions per iteration
 #ifdef PT_WALK_PROFILE
         if ((tid & 63u) == 0u) {
             const bool fl = (uint32_t)__popcll(m_pend) >= flush_at || m_inner == 0ull;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
     uint32_t n_cands = 0, n_paths = 0, n_not_unit = 0; // per-lane counts (widened when the wave sums them)
     unsigned long long w_rays_traced = 0;             // wave-uniform
     uint32_t n_wave_steps = 0, n_flush_iters = 0; // wave-uniform (SALU) profile counters
-    unsigned long long w_tree_cands = 0, w_tree_boxes = 0;  // wave-uniform: exact tests and box tests of the tree walk
+    unsigned long long w_tree_cands = 0, w_tree_boxes = 0, w_tree_iters = 0;  // wave-uniform: exact tests, box tests and loop iterations of the tree walk
     unsigned long long t_flush = 0;               // PT_PHASE_TIMING builds only
 #ifdef PT_PHASE_TIMING
     unsigned long long t_phase[5] = {0, 0, 0, 0, 0}; // A refill, B filter scan, B flush, C shade, whole
@@ -835,10 +835,10 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
             }
             if (TREE_LDS)
                 scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max,
-                                  t_closest, t_hit, w_tree_cands, n_flush_iters, w_tree_boxes);
+                                  t_closest, t_hit, w_tree_cands, w_tree_iters, w_tree_boxes);
             else
                 scene_is_hit_tree(TreeInGlobal{P.tnodes, P.tgeom, P.tprim, s_mask}, t_cur, t_sp, t_pend, P.tree_exit_at, P.tree_flush_at, tid, o, d, a, P.t_min, P.t_max, t_closest,
-                                  t_hit, w_tree_cands, n_flush_iters, w_tree_boxes);
+                                  t_hit, w_tree_cands, w_tree_iters, w_tree_boxes);
             tracing = tracing && t_cur == kNone && t_sp == 0u && t_pend == kNone; // lanes still walking skip this step's shading and keep their ray
             closest = t_closest; hit = t_hit;
         } else
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(kBlock, TREE ? (MULTI_TILE ? PT_TREE_GLOBAL_WAVES :
         if (w_not_unit) atomicAdd(&P.counters[CNT_NOT_UNIT], w_not_unit);
         if (TREE) atomicAdd(&P.counters[CNT_BOX_TESTS], w_boxes);
         atomicAdd(&P.counters[CNT_WAVE_STEPS], (unsigned long long)n_wave_steps);
-        atomicAdd(&P.counters[CNT_FLUSH_ITERS], (unsigned long long)n_flush_iters);
+        atomicAdd(&P.counters[CNT_FLUSH_ITERS], TREE ? w_tree_iters : (unsigned long long)n_flush_iters);
     }
 }
 
@@ -1791,8 +1791,8 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     const float a = vlen2(d);
     float closest = t_max;
     int hit = -1;
-    unsigned long long n_cands = 0, n_boxes = 0;
-    uint32_t sp = 0, n_iters = 0;
+    unsigned long long n_cands = 0, n_boxes = 0, n_iters = 0;
+    uint32_t sp = 0;
     if (LDS) {
         uint32_t cur = live ? TreeInLds::ref16(root) : TreeInLds::kNone, pend = TreeInLds::kNone;
         scene_is_hit_tree(TreeInLds{s_tboxes, s_tchild, s_tgeom, s_tprim, s_tstack}, cur, sp, pend, 0u, flush_at, tid, o, d, a, t_min, t_max, closest, hit, n_cands, n_iters, n_boxes);
