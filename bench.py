@@ -240,7 +240,7 @@ def main():
             return flops / (ms * 1e-3) / PEAK_FP32_VALU if ms > 0 else None
 
         # ---- what each kernel EXECUTED (active lanes' arithmetic) --------------------------------------------------
-        if tree["nodes"]:   # ~30 FLOP per ray-box test (6 differences, the margin, 6 slab products, min/max chains), 18 per exact sphere test, 60 per ray
+        if tree["nodes"]:   # ~30 FLOP per ray-box test (24 instructions: 3 differences to the centre, the margin, 3 grown half extents, 3 centre products, 6 FMAs to the slab ends, min/max chains; kept at the round-2 figure of 30), 18 per exact sphere test, 60 per ray
             mk_exec = boxes_l * 30.0 + (cands_l - pcands_l) * 18.0 + mk_rays * 60.0
             mk_basis = ("executed: %.1f ray-box tests x 30 FLOP + %.1f exact sphere tests x 18 FLOP + 60 FLOP per ray the megakernel traces (device counts)"
                         % (boxes_l / max(mk_rays, 1.0), (cands_l - pcands_l) / max(mk_rays, 1.0)))
