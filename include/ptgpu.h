@@ -240,7 +240,10 @@ enum {
     PT_FN_SCENE_HIT_TREE = 11, /* scene.zig:96 through the sphere tree of large scenes (PT_LIMIT_TREE_MIN_SPHERES): in/out as
                               PT_FN_SCENE_HIT; PT_ERR_UNSUPPORTED when the uploaded scene has no tree */
     PT_FN_SAMPLE_DISK = 12, /* camera.zig:113-120 or its direct equivalent: in: sampler (PT_SAMPLER_*), xi[16] (17)  out: p, n_used (4) */
-    PT_FN_SAMPLE_BALL = 13  /* material.zig:27-34 or its direct equivalent: in: sampler, xi[16] (17)                  out: p, n_used (4) */
+    PT_FN_SAMPLE_BALL = 13, /* material.zig:27-34 or its direct equivalent: in: sampler, xi[16] (17)                  out: p, n_used (4) */
+    PT_FN_TREE_BOX_SAFETY = 14 /* what the sphere tree rests on (scene.zig:96-110 must see every sphere the exact test accepts): the ray
+                              visits every node; for each sphere Sphere.is_hit accepts at t, every ancestor's box must pass the walk's box
+                              test on (t_min, t).  in: o,d (6)  out: spheres accepted, (sphere, box) pairs checked, pairs FAILED (must be 0), 0 */
 };
 int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32_t n,
                      float t_min, float t_max);

@@ -39,11 +39,12 @@ PT_SAMPLER_REJECTION, PT_SAMPLER_DIRECT = 0, 1
 
 (PT_FN_CAST_RAY, PT_FN_SPHERE_HIT, PT_FN_SCENE_HIT, PT_FN_SCATTER, PT_FN_REFRACT, PT_FN_SCHLICK, PT_FN_REFLECT,
  PT_FN_LERP, PT_FN_PHILOX, PT_FN_SCENE_HIT_FILTERED, PT_FN_FILTER_BIT, PT_FN_SCENE_HIT_TREE, PT_FN_SAMPLE_DISK,
- PT_FN_SAMPLE_BALL) = range(14)
+ PT_FN_SAMPLE_BALL, PT_FN_TREE_BOX_SAFETY) = range(15)
 FN_STRIDES = {  # fn -> (floats in, floats out) per record, as include/ptgpu.h documents
     PT_FN_CAST_RAY: (18, 7), PT_FN_SPHERE_HIT: (12, 8), PT_FN_SCENE_HIT: (6, 8), PT_FN_SCATTER: (27, 4),
     PT_FN_REFRACT: (7, 4), PT_FN_SCHLICK: (2, 1), PT_FN_REFLECT: (6, 3), PT_FN_LERP: (9, 4), PT_FN_PHILOX: (5, 4), PT_FN_SCENE_HIT_FILTERED: (6, 8),
-    PT_FN_FILTER_BIT: (10, 3), PT_FN_SCENE_HIT_TREE: (6, 8), PT_FN_SAMPLE_DISK: (17, 4), PT_FN_SAMPLE_BALL: (17, 4)}
+    PT_FN_FILTER_BIT: (10, 3), PT_FN_SCENE_HIT_TREE: (6, 8), PT_FN_SAMPLE_DISK: (17, 4), PT_FN_SAMPLE_BALL: (17, 4),
+    PT_FN_TREE_BOX_SAFETY: (6, 4)}
 
 # pt_sphere: 36 bytes
 SPHERE_DTYPE = np.dtype(

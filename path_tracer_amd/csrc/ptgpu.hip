@@ -416,7 +416,10 @@ constexpr uint32_t kTreeLeaf = PT_TREE_LEAF; // spheres per leaf (at most 8: thr
 static_assert(kTreeLeaf >= 1 && kTreeLeaf <= 8, "leaf count field");
 constexpr uint32_t kTreeStack = 24;        // stack entries per lane = deepest tree walked (set_scene falls back to the scan beyond it)
 constexpr uint32_t kTreeLeafBit = 0x80000000u, kTreeNone = 0xffffffffu; // leaf ref: bit 31 | (count - 1) << 28 | first slot of the leaf arrays
-constexpr float kTreeKappa = 8e-3f;
+#ifndef PT_TREE_KAPPA
+#define PT_TREE_KAPPA 8e-3f // (tools/build_variant.sh with 0: the negative control of PT_FN_TREE_BOX_SAFETY — boxes that are not grown do fail it)
+#endif
+constexpr float kTreeKappa = PT_TREE_KAPPA;
 
 __device__ __forceinline__ bool tree_box(V3 o, V3 inv, float bcx, float bcy, float bcz, float bhx, float bhy, float bhz, float t_lo, float t_hi,
                                          float &t_near) {
@@ -1807,6 +1810,55 @@ __global__ __launch_bounds__(kBlock) void pt_debug_scene_hit_tree(const float *i
     w[0] = (float)hit; w[1] = (hit >= 0) ? closest : 0.f; w[2] = p.x; w[3] = p.y; w[4] = p.z; w[5] = nn.x; w[6] = nn.y; w[7] = nn.z;
 }
 
+// PT_FN_TREE_BOX_SAFETY: the property the tree walk rests on, checked pair by pair instead of through closest hits.  The ray visits
+// EVERY node (no pruning); for every sphere the exact test accepts at t, the box of every ancestor must pass tree_box — the
+// function the walk uses — with the interval clipped to (t_min, t): the tightest interval under which the walk could still need
+// that sphere (it skips a box against the closest hit so far, which is >= t until the sphere is tested).  out: spheres accepted,
+// (sphere, ancestor box) pairs checked, pairs whose box test FAILED (must be 0), 0.
+__global__ __launch_bounds__(kBlock) void pt_debug_tree_box_safety(const float *in, float *out, uint32_t n, const TreeNode *nodes, const float4 *tgeom,
+                                                                   uint32_t root, float t_min, float t_max) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *r = in + (size_t)i * 6;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const float a = vlen2(d);
+    const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); // as the walk takes it
+    uint32_t path_node[kTreeStack + 1], path_next[kTreeStack + 1]; // the inner nodes from the root down and which child comes next
+    uint32_t sp = 0;
+    float accepted = 0.f, pairs = 0.f, failed = 0.f;
+    auto child_box = [&](uint32_t node, uint32_t c, float t_hi) -> bool {
+        const TreeNode nd = nodes[node];
+        float t_near;
+        return c == 0u ? tree_box(o, inv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, t_min, t_hi, t_near)
+                       : tree_box(o, inv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, t_min, t_hi, t_near);
+    };
+    auto leaf = [&](uint32_t ref) {
+        const uint32_t first = TreeInGlobal::first(ref), cnt = TreeInGlobal::count(ref);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 g = tgeom[first + k];
+            float t;
+            if (!sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, t_min, t_max, t)) continue;
+            accepted += 1.f;
+            for (uint32_t f = 0; f < sp; ++f) { // path_next[f] - 1 is the child of path_node[f] this leaf hangs under
+                pairs += 1.f;
+                if (!child_box(path_node[f], path_next[f] - 1u, t)) failed += 1.f;
+            }
+        }
+    };
+    if (root & kTreeLeafBit) leaf(root);
+    else { path_node[0] = root; path_next[0] = 0u; sp = 1; }
+    while (sp > 0u) {
+        if (path_next[sp - 1u] == 2u) { --sp; continue; }
+        const uint32_t c = path_next[sp - 1u]++;
+        const uint4 ch = nodes[path_node[sp - 1u]].ch;
+        const uint32_t ref = c == 0u ? ch.x : ch.y;
+        if (ref & kTreeLeafBit) leaf(ref);
+        else if (sp <= kTreeStack) { path_node[sp] = ref; path_next[sp] = 0u; ++sp; }
+    }
+    float *w = out + (size_t)i * 4;
+    w[0] = accepted; w[1] = pairs; w[2] = failed; w[3] = 0.f;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -2822,12 +2874,13 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     case PT_FN_PHILOX: in_stride = 5; out_stride = 4; break;
     case PT_FN_FILTER_BIT: in_stride = 10; out_stride = 3; break;
     case PT_FN_SCENE_HIT_TREE: in_stride = 6; out_stride = 8; break;
+    case PT_FN_TREE_BOX_SAFETY: in_stride = 6; out_stride = 4; break;
     case PT_FN_SAMPLE_DISK: case PT_FN_SAMPLE_BALL: in_stride = 17; out_stride = 4; break;
     default: return PT_ERR_UNSUPPORTED;
     }
     if ((fn == PT_FN_SCENE_HIT || fn == PT_FN_SCENE_HIT_FILTERED) && !ctx->d_geom) return PT_ERR_BAD_ARG;
     if (fn == PT_FN_CAST_RAY && !ctx->have_camera) return PT_ERR_BAD_ARG;
-    if (fn == PT_FN_SCENE_HIT_TREE && ctx->tree_nodes == 0u) return PT_ERR_UNSUPPORTED;
+    if ((fn == PT_FN_SCENE_HIT_TREE || fn == PT_FN_TREE_BOX_SAFETY) && ctx->tree_nodes == 0u) return PT_ERR_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *d_in = nullptr, *d_out = nullptr, *d_thr = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_in, in_stride * n * sizeof(float)));
@@ -2854,6 +2907,9 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
                 hipLaunchKernelGGL(pt_debug_scene_hit_tree<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
                                    (const TreeNode *)ctx->d_tnodes, ctx->tree_nodes, (const float4 *)ctx->d_tgeom, (const uint32_t *)ctx->d_tprim, ctx->nspheres,
                                    ctx->tree_root, (const float4 *)ctx->d_geom, t_min, t_max, 8u);
+        } else if (fn == PT_FN_TREE_BOX_SAFETY) {
+            hipLaunchKernelGGL(pt_debug_tree_box_safety, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, (const float *)d_in, d_out, n,
+                               (const TreeNode *)ctx->d_tnodes, (const float4 *)ctx->d_tgeom, ctx->tree_root, t_min, t_max);
         } else if (fn == PT_FN_SCENE_HIT_FILTERED) {
             const uint32_t blocks = (n + kBlock - 1) / kBlock;
             if (ctx->n_pad > (uint32_t)kTile)

@@ -119,6 +119,37 @@ def test_closest_hits_of_adversarial_scenes(gpu):
     assert hits > 100000
 
 
+def test_no_box_rejects_a_sphere_the_exact_test_accepts(gpu):
+    """The safety of the tree, pair by pair (PT_FN_TREE_BOX_SAFETY) instead of through closest hits, where a wrongly skipped box
+    only shows when it held THE closest sphere: every ray visits every node, and for each sphere Sphere.is_hit accepts at t, the
+    box of every ancestor must pass the walk's own box test on (t_min, t).  Reference scenes and the adversarial ones (radii 1e-3
+    to 5000 and negative, coincident and concentric spheres, coordinates ~1e4, grazing / axis-aligned / non-unit rays from surfaces
+    and centres)."""
+    from path_tracer_amd import _lib, host
+    rng = np.random.default_rng(77)
+    scenes = [host.Scene().setupScene(456, 21).spheres, host.Scene().sceneSynthetic(3000, 2).spheres]
+    for trial in range(24):
+        n = int(rng.choice([5, 40, 300, 2500]))
+        sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
+        spread = float(rng.choice([0.0, 4.0, 15.0, 60.0]))
+        off = float(rng.choice([0.0, 0.0, 1.0e4]))
+        sp["cx"], sp["cy"], sp["cz"] = off + rng.normal(0, spread, n), rng.normal(0, spread, n), rng.normal(0, spread, n) - off
+        sp["radius"] = rng.choice([1e-3, 0.02, 0.2, 0.5, 3.0, 40.0, -0.7], n)
+        if trial % 3 == 0:
+            sp[0] = (0, -5000, 0, 5000, 0, 0.5, 0.5, 0.5, 0)
+        sp[2] = sp[n - 1] = sp[n // 2]
+        scenes.append(sp)
+    accepted = pairs = 0
+    for sp in scenes:
+        _set_scene(gpu, sp, 1)
+        assert gpu.tree_info()["nodes"] >= 1
+        for t_min, t_max in ((0.001, 1.0e6), (0.0, 100.0), (-2.0, 1000.0)):
+            out = gpu.debug_eval(_lib.PT_FN_TREE_BOX_SAFETY, _rays(rng, sp, 20000), t_min, t_max)
+            assert np.all(out[:, 2] == 0), (len(sp), t_min, int(out[:, 2].sum()), np.flatnonzero(out[:, 2])[:5])
+            accepted += int(out[:, 0].sum()); pairs += int(out[:, 1].sum())
+    assert accepted > 300_000 and pairs > 2_000_000, (accepted, pairs)
+
+
 def test_non_finite_rays_hit_nothing_either_way(gpu):
     from path_tracer_amd import host
     sp = host.Scene().sceneSynthetic(1000, 3).spheres
