@@ -254,6 +254,15 @@ int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *out, uint32
  * (vec3.zig:61-64 unitVector), 3 the unit-length test of illumination.zig:28 taken on |d|^2.  About 0.1 s each. */
 int ptgpu_debug_exhaustive(ptgpu_ctx *ctx, int which, uint64_t *mismatches);
 
+/* The property the primary pass's candidate lists rest on, checked sphere by sphere: runs the lists and the primary
+ * pass of `cfg` (stochastic mode, the reference's samplers) with every camera ray and every second-bounce ray that is about to use a
+ * list ALSO given the reference's exact test on every sphere of the scene (scene.zig:96-110 as written); each sphere that test accepts
+ * must be in the list.  No frame is produced.  out: [0] spheres accepted for camera rays, [1] of them NOT in list A (must be 0),
+ * [2] accepted for second rays, [3] NOT in list B (must be 0), [4] rays whose closest hit (index or t) differs from the full scan's
+ * (must be 0), [5] camera rays checked, [6] second rays checked.  PT_ERR_UNSUPPORTED when the configuration has no primary pass.
+ * O(paths x spheres): a test tool.  No counterpart in the reference. */
+int ptgpu_debug_list_safety(ptgpu_ctx *ctx, const pt_config *cfg, uint64_t out[7]);
+
 /* ---- multi-GPU: the GPUs of one node behind one handle ---------------------------------
  * Replaces the reference's thread block, main.zig:142-165 (T threads over contiguous pixel chunks of
  * multithreading.zig:40-44, then join): one host thread per GPU drives that GPU's own context and

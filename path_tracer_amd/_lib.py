@@ -86,7 +86,7 @@ assert C.sizeof(pt_camera) == 76 and C.sizeof(pt_config) == 112 and C.sizeof(pt_
 EXPORTS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_scene", "ptgpu_set_camera", "ptgpu_render_sum_device",
            "ptgpu_render_sum_device_noalloc", "ptgpu_noalloc_scratch_bytes", "ptgpu_set_limit", "ptgpu_trim", "ptgpu_work_bytes",
            "ptgpu_render_sum_host", "ptgpu_resolve_device", "ptgpu_render_ppm", "ptgpu_render_mean_host",
-           "ptgpu_debug_eval", "ptgpu_debug_exhaustive", "ptgpu_get_stats", "ptgpu_scene_info", "ptgpu_tree_info", "ptgpu_debug_tree_check", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
+           "ptgpu_debug_eval", "ptgpu_debug_exhaustive", "ptgpu_debug_list_safety", "ptgpu_get_stats", "ptgpu_scene_info", "ptgpu_tree_info", "ptgpu_debug_tree_check", "ptgpu_strerror", "ptgpu_last_hip_error", "ptgpu_device_info",
            "ptgpu_abi_version",
            "ptgpu_multi_create", "ptgpu_multi_destroy", "ptgpu_multi_num_gpus", "ptgpu_multi_uses_rccl", "ptgpu_multi_ctx",
            "ptgpu_multi_set_scene", "ptgpu_multi_set_camera", "ptgpu_multi_render_sum_host", "ptgpu_multi_render_ppm",
@@ -131,6 +131,7 @@ def load():
     L.ptgpu_render_ppm.argtypes = [vp, C.POINTER(pt_config), vp, C.c_size_t, C.c_uint32, C.c_uint32]
     L.ptgpu_debug_eval.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, C.c_float, C.c_float]
     L.ptgpu_debug_exhaustive.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.ptgpu_debug_list_safety.argtypes = [vp, C.POINTER(pt_config), C.POINTER(C.c_uint64)]
     L.ptgpu_get_stats.argtypes = [vp, C.POINTER(pt_stats)]
     L.ptgpu_scene_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ptgpu_tree_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -1353,7 +1353,12 @@ __global__ __launch_bounds__(256) void pt_primary_lists(const ListCam C, uint32_
 // One thread per path of the launch, in record order (item-major, the item's samples consecutive): the
 // camera ray (renderers/ppm_image.zig:50-51,61-63), Scene.is_hit over the pixel's list, one radiance step
 // (illumination.zig:76-90 at depth 0).
-template <int MODE, bool MULTI_TILE>
+// CHECK (ptgpu_debug_list_safety; never in a render): at both list loops the ray is ALSO given the exact test on every sphere of the
+// scene, and each sphere that test accepts must be in the list the path is about to use — the property the lists rest on, checked
+// sphere by sphere under exactly the conditions pt_primary uses a list, instead of through frames (where a missing sphere only shows
+// when it was the closest).  Counted: accepted spheres and missing ones per list, closest hits that differ.
+enum { CNT_CHECK_ACC_A = 24, CNT_CHECK_MISS_A = 25, CNT_CHECK_ACC_B = 26, CNT_CHECK_MISS_B = 27, CNT_CHECK_DIFF = 28, CNT_CHECK_RAYS_A = 29, CNT_CHECK_RAYS_B = 30 }; // (the phase-timing slots)
+template <int MODE, bool MULTI_TILE, bool CHECK = false>
 __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec) {
     constexpr bool DET = MODE == kModeDet, DIRECT = MODE == kModeDirect;
     // scenes of one tile keep the sphere tables in LDS (19 KiB; the grid-stride loop reuses them): the candidate loop's
@@ -1375,6 +1380,7 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
     // grid-stride: the counters below cost three atomics per WAVE OF THE GRID, not per 64 paths (same-address
     // atomics serialise in L2: one per wave of paths made this kernel 15 times slower)
     uint32_t rays = 0, rays2 = 0, cands = 0, not_unit = 0;
+    uint32_t chk[5] = {0, 0, 0, 0, 0}; // CHECK: accepted / missing of list A, of list B, closest hits that differ
 #ifdef PT_PHASE_TIMING
     unsigned long long t_pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // path start, list trace, shade, record write, whole
     const unsigned long long tpp_begin = __builtin_amdgcn_s_memtime();
@@ -1467,6 +1473,20 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
                         for (uint32_t i = 0; i < 4u; ++i) test_entry(ent[4u * q + i]);
                     }
                     if (depth) rays2++; else rays++;
+                    if (CHECK) {
+                        float c_closest = P.t_max; int c_hit = -1;
+                        for (uint32_t j = 0; j < P.nspheres; ++j) { // scene.zig:96-110 as written
+                            const float4 g = geom_of(j);
+                            float t;
+                            if (!sphere_near_root(o, d, a, g.x, g.y, g.z, g.w, P.t_min, P.t_max, t)) continue;
+                            if (t < c_closest) { c_closest = t; c_hit = (int)j; }
+                            bool in_list = false, open = true;
+                            for (uint32_t i = 0; i < 16u; ++i) { open = open && ent[i] != kListEnd; in_list = in_list || (open && ent[i] == j); }
+                            chk[depth ? 2 : 0]++;
+                            if (!in_list) chk[depth ? 3 : 1]++;
+                        }
+                        if (c_hit != hit || (hit >= 0 && __float_as_uint(c_closest) != __float_as_uint(closest))) chk[4]++;
+                    }
                     PT_STAMP(tl1);
                     PP_ACC(1 + (depth ? 2 : 0), tl0, tl1);
                     V3 color = v3(0.f, 0.f, 0.f);
@@ -1540,6 +1560,15 @@ __global__ __launch_bounds__(256) void pt_primary(const KParams P, uint32_t nrec
     }
 #endif
     const unsigned long long w_rays = wave_sum_u64(rays), w_rays2 = wave_sum_u64(rays2), w_cands = wave_sum_u64(cands), w_nu = wave_sum_u64(not_unit);
+    if (CHECK) {
+        unsigned long long w_chk[5];
+        for (int i = 0; i < 5; ++i) w_chk[i] = wave_sum_u64(chk[i]);
+        if ((threadIdx.x & 63u) == 0u) {
+            for (int i = 0; i < 5; ++i) if (w_chk[i]) atomicAdd(&P.counters[CNT_CHECK_ACC_A + i], w_chk[i]);
+            if (w_rays) atomicAdd(&P.counters[CNT_CHECK_RAYS_A], w_rays);
+            if (w_rays2) atomicAdd(&P.counters[CNT_CHECK_RAYS_B], w_rays2);
+        }
+    }
     if ((threadIdx.x & 63u) == 0u) {
         if (w_rays) { atomicAdd(&P.counters[CNT_RAYS], w_rays + w_rays2); atomicAdd(&P.counters[CNT_PRIMARY_RAYS], w_rays); }
         if (w_rays2) atomicAdd(&P.counters[CNT_LIST2_RAYS], w_rays2);
@@ -1896,6 +1925,7 @@ struct ptgpu_ctx {
     uint32_t tree_min_spheres = 256u;                 // PT_LIMIT_TREE_MIN_SPHERES (measured: the walk in LDS overtakes the scan between 150 and 250 spheres)
     int resident_tree[2][2] = {{0, 0}, {0, 0}};      // [det][multi]: workgroups per CU of the tree variants (multi = 0: tree staged in LDS)
     bool have_camera = false;
+    bool debug_list_check = false; // ptgpu_debug_list_safety: render_sum_impl runs the lists and pt_primary<.., CHECK> only
     Cam cam;
     float *d_part = nullptr; size_t part_bytes = 0;
     uint32_t *d_stack = nullptr; size_t stack_bytes = 0;
@@ -2452,6 +2482,9 @@ static ListCam make_list_cam(const Cam &c, uint32_t width, uint32_t height) {
     // (col + xi) and (height - row + 1 + xi) are rounded to f32 before the division: up to an ulp of the index outside the box
     const double wh = (double)(width > height ? width : height);
     L.Rp = 0.5 * (len[2] / (double)width + len[3] / (double)height) * (1.0 + 1e-3 + 8.0 * wh * ulp);
+#ifdef PT_LIST_NEGATIVE_CONTROL // tools/build_variant.sh: the pixel footprint taken at half its size — ptgpu_debug_list_safety must then report missing spheres
+    L.Rp *= 0.5;
+#endif
     const double mag = len[0] + len[1] + len[2] + len[3] + L.Rl;
     L.e_o = 16.0 * ulp * (len[0] + L.Rl);
     L.e_d = 32.0 * ulp * mag;
@@ -2489,6 +2522,10 @@ template <int MODE>
 static void launch_primary_m(bool multi, uint32_t pgrid, hipStream_t stream, const KParams &P, uint32_t nrec) {
     if (multi) hipLaunchKernelGGL((pt_primary<MODE, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
     else hipLaunchKernelGGL((pt_primary<MODE, false>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+}
+static void launch_primary_check(bool multi, uint32_t pgrid, hipStream_t stream, const KParams &P, uint32_t nrec) {
+    if (multi) hipLaunchKernelGGL((pt_primary<kModeRejection, true, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
+    else hipLaunchKernelGGL((pt_primary<kModeRejection, false, true>), dim3(pgrid), dim3(256), 0, stream, P, nrec);
 }
 static void launch_primary(int mode, bool multi, uint32_t pgrid, hipStream_t stream, const KParams &P, uint32_t nrec) {
     if (mode == kModeDet) launch_primary_m<kModeDet>(multi, pgrid, stream, P, nrec);
@@ -2683,15 +2720,16 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
             if (timed) HIP_TRY(ctx, hipEventRecord(evs[1], stream));
             const uint32_t nrec = P.npix * nchunks * chunk; // <= 0xf0000000 by the segment size
             const uint32_t pgrid = std::min<uint32_t>((nrec + 255u) / 256u, (uint32_t)ctx->compute_units * 32u);
-            launch_primary(mode, multi, pgrid, stream, P, nrec);
+            if (ctx->debug_list_check) launch_primary_check(multi, pgrid, stream, P, nrec);
+            else launch_primary(mode, multi, pgrid, stream, P, nrec);
             HIP_TRY(ctx, hipGetLastError());
             if (timed) HIP_TRY(ctx, hipEventRecord(evs[2], stream));
         }
-        launch_megakernel(mode, multi, grid, stream, P);
+        if (!ctx->debug_list_check) launch_megakernel(mode, multi, grid, stream, P); // (the check stops after the primary pass)
         HIP_TRY(ctx, hipGetLastError());
         if (timed) HIP_TRY(ctx, hipEventRecord(evs[3], stream));
         if (one_seg) HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream)); // one segment: ev0..ev1 is the tracing kernels alone
-        if (nchunks > 1) {
+        if (nchunks > 1 && !ctx->debug_list_check) {
             const uint32_t n3 = P.npix * 3u;
             hipLaunchKernelGGL(pt_sum_chunks, dim3((n3 + 255u) / 256u), dim3(256), 0, stream, (const float *)ws.part, slot0, P.npix, nchunks,
                                cfg->idx_start, cfg->idx_stop, cfg->tile_pixels, cfg->tile_count, cfg->tile_index, d_rgb_sum);
@@ -2931,6 +2969,19 @@ extern "C" int ptgpu_debug_eval(ptgpu_ctx *ctx, int fn, const float *in, float *
     (void)hipFree(d_in); (void)hipFree(d_out);
     if (d_thr) (void)hipFree(d_thr);
     return rc;
+}
+
+extern "C" int ptgpu_debug_list_safety(ptgpu_ctx *ctx, const pt_config *cfg, uint64_t out[7]) {
+    if (!ctx || !cfg || !out) return PT_ERR_BAD_ARG;
+    if (cfg->mode != 0u || cfg->sampler != PT_SAMPLER_REJECTION) return PT_ERR_UNSUPPORTED; // the check kernel is built for the default mode
+    ctx->debug_list_check = true;
+    // (the frame argument is not written in this mode: no megakernel, no chunk sums; any non-null device pointer will do)
+    const int rc = render_sum_impl(ctx, cfg, reinterpret_cast<float *>(ctx->d_counters), nullptr, false);
+    ctx->debug_list_check = false;
+    if (rc != PT_OK) return rc;
+    if (ctx->stats.primary_rays == 0u) return PT_ERR_UNSUPPORTED; // no primary pass for this scene / configuration / limit: nothing was checked
+    for (int i = 0; i < 7; ++i) out[i] = ctx->h_counters[CNT_CHECK_ACC_A + i];
+    return PT_OK;
 }
 
 extern "C" int ptgpu_debug_exhaustive(ptgpu_ctx *ctx, int which, uint64_t *mismatches) {

@@ -115,6 +115,14 @@ class GpuContext:
                                        float(t_max)), "ptgpu_debug_eval")
         return out
 
+    def debug_list_safety(self, cfg):
+        """ptgpu_debug_list_safety: dict of the check's counts (missing_a, missing_b and closest_differs must be 0)"""
+        cfg = self.as_config(cfg)
+        out = (C.c_uint64 * 7)()
+        check(self._L.ptgpu_debug_list_safety(self._h, C.byref(cfg), out), "ptgpu_debug_list_safety")
+        keys = ("accepted_a", "missing_a", "accepted_b", "missing_b", "closest_differs", "rays_a", "rays_b")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def debug_exhaustive(self, which):
         """ptgpu_debug_exhaustive: mismatches of a lean f32 sequence against the compiler's over all 2^32 inputs (must be 0)"""
         bad = C.c_uint64(1)

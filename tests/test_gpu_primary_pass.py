@@ -152,6 +152,55 @@ def test_random_cameras_and_adversarial_scenes_on_off(gpu):
     assert second > 0.02 * total            # and second-bounce lists were used
 
 
+def test_no_list_misses_a_sphere_the_exact_test_accepts(gpu):
+    """The property the candidate lists rest on, sphere by sphere (ptgpu_debug_list_safety) instead of through frames, where a missing
+    sphere only shows when it was the closest: pt_primary's own rays — its jitter, lens draws and scattered directions, under exactly the
+    conditions it uses a list — also get the reference's exact test on EVERY sphere; each accepted sphere must be in the list, and the
+    closest hit must be the full scan's.  Reference scenes, random cameras over adversarial scenes (as above), a many-tile scene whose
+    lists are built by the tree walk."""
+    from path_tracer_amd import _lib, host
+    rng = np.random.default_rng(12)
+    total = dict(accepted_a=0, missing_a=0, accepted_b=0, missing_b=0, closest_differs=0, rays_a=0, rays_b=0)
+
+    def run(cfg, may_have_no_list=False):
+        try:
+            r = gpu.debug_list_safety(cfg)
+        except _lib.PtGpuError as e:             # PT_ERR_UNSUPPORTED: no pixel of this camera got a list (every list overflowed)
+            assert may_have_no_list and e.status == _lib.PT_ERR_UNSUPPORTED, e
+            return
+        assert r["missing_a"] == 0 and r["missing_b"] == 0 and r["closest_differs"] == 0, r
+        for k in total:
+            total[k] += r[k]
+
+    for n_scene, width in ((18, 96), (19, 96), (20, 96), (21, 160)):
+        gpu.set_scene(host.Scene().setupScene(456, n_scene).spheres)
+        gpu.set_camera(host.Camera.preset(n_scene).pod)
+        run(host.make_pt_config(host.Image(width), host.RayTracerConfig(subpixels=4, rays_per_subsample=8, rebounds=50), seed=3, chunk=16))
+    img = host.Image(64)
+    rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=8, t_min=0.001, t_max=1.0e6, rebounds=8)
+    for trial in range(48):
+        n = int(rng.choice([3, 40, 300, 700]))
+        sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
+        spread = float(rng.choice([4.0, 15.0, 60.0]))
+        sp["cx"], sp["cy"], sp["cz"] = rng.normal(0, spread, n), rng.normal(0, spread, n), rng.normal(0, spread, n)
+        sp["radius"] = rng.choice([1e-3, 0.02, 0.2, 0.5, 3.0, 40.0, -0.7], n)
+        sp["kind"] = rng.choice([0, 1, 2], n, p=[0.6, 0.25, 0.15])
+        sp["ar"], sp["ag"], sp["ab"] = rng.random(n), rng.random(n), rng.random(n)
+        sp["param"] = np.where(sp["kind"] == 2, 1.5, 0.3 * rng.random(n))
+        sp[0] = (0, -5000, 0, 5000, 0, 0.5, 0.5, 0.5, 0)
+        if n > 3:
+            sp[1] = (2000, 0, 0, 1.0, 0, 1, 1, 1, 0)
+            sp[2] = sp[3] = (1, 1, 1, 0.25, 0, 1, 0.5, 0.2, 0)
+        gpu.set_scene(sp)
+        gpu.set_camera(_random_camera(rng, host, img.aspect_ratio).pod)
+        run(host.make_pt_config(img, rt, seed=300 + trial, chunk=16), may_have_no_list=True)
+    gpu.set_scene(host.Scene().sceneSynthetic(3000, 7).spheres)         # lists by the tree walk (pt_primary_lists<true>), in walk order
+    gpu.set_camera(host.Camera.preset(21).pod)
+    run(host.make_pt_config(host.Image(96), host.RayTracerConfig(subpixels=2, rays_per_subsample=4, rebounds=20), seed=4, chunk=4))
+    assert total["rays_a"] > 3_000_000 and total["rays_b"] > 300_000, total
+    assert total["accepted_a"] > 1_000_000 and total["accepted_b"] > 100_000, total
+
+
 def test_many_tile_scene_on_off(gpu):
     """More spheres than one LDS tile: the primary pass reads the exact geometry from global memory."""
     from path_tracer_amd import host
