@@ -15,7 +15,7 @@ def main():
     g = GpuContext(0)
     img = host.Image(64)
     rt = host.RayTracerConfig(subpixels=4, rays_per_subsample=8, t_min=0.001, t_max=1.0e6, rebounds=8)
-    t0, trials, listed, second, total = time.time(), 0, 0, 0, 0
+    t0, trials, listed, second, total, accepted = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
         n = int(rng.choice([3, 40, 300, 512, 700, 4000]))
         sp = np.zeros(n, dtype=_lib.SPHERE_DTYPE)
@@ -37,6 +37,13 @@ def main():
         g.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, 1)
         g.set_scene(sp)
         a = g.render_sum(cfg, allow_not_unit=True); sa = g.stats()
+        if sa.primary_rays:  # the lists' property sphere by sphere (ptgpu_debug_list_safety), on the same scene, camera and draws
+            chk = g.debug_list_safety(cfg)
+            if chk["missing_a"] or chk["missing_b"] or chk["closest_differs"]:
+                print("LIST CHECK FAILED trial %d n=%d: %s" % (trials, n, chk), flush=True)
+                np.save("gpurun_out/stress_lists_scene.npy", sp)
+                sys.exit(1)
+            accepted += chk["accepted_a"] + chk["accepted_b"]
         g.set_limit(_lib.PT_LIMIT_PRIMARY_BYTES, 0)
         g.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, 0)
         g.set_scene(sp)
@@ -49,7 +56,7 @@ def main():
         trials += 1
         if trials % 50 == 0:
             print("%d renders pairs, listed %.2f, second bounce %.2f of the paths, %.0f s" % (trials, listed / total, second / total, time.time() - t0), flush=True)
-    print("OK: %d scenes x cameras, listed %.2f, second bounce %.2f of the paths, no mismatch" % (trials, listed / total, second / total))
+    print("OK: %d scenes x cameras, listed %.2f, second bounce %.2f of the paths, no mismatch; %.1f M accepted spheres all in their lists" % (trials, listed / total, second / total, accepted * 1e-6))
 
 
 main()

@@ -35,7 +35,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     g = GpuContext(0)
     g.set_limit(_lib.PT_LIMIT_TREE_MIN_SPHERES, 1)
-    t0, trials, rays_total, hits = time.time(), 0, 0, 0
+    t0, trials, rays_total, hits, pairs = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         sp = scene(rng)
         g.set_scene(sp)
@@ -51,10 +51,17 @@ def main():
                 np.save("gpurun_out/stress_tree_scene.npy", sp); np.save("gpurun_out/stress_tree_rays.npy", rays)
                 sys.exit(1)
             rays_total += len(rays); hits += int((a[:, 0] >= 0).sum())
+            c = g.debug_eval(_lib.PT_FN_TREE_BOX_SAFETY, rays[:20000], t_min, t_max)   # every accepted sphere against every ancestor's box
+            if c[:, 2].any():
+                i = int(np.flatnonzero(c[:, 2])[0])
+                print("BOX FAILED trial %d n=%d ray %s: %s" % (trials, len(sp), rays[i], c[i]), flush=True)
+                np.save("gpurun_out/stress_tree_scene.npy", sp); np.save("gpurun_out/stress_tree_rays.npy", rays)
+                sys.exit(1)
+            pairs += int(c[:, 1].sum())
         trials += 1
         if trials % 20 == 0:
             print("%d scenes, %.1f M rays, %.1f M hits, %.0f s" % (trials, rays_total * 1e-6, hits * 1e-6, time.time() - t0), flush=True)
-    print("OK: %d scenes, %.1f M rays, %.1f M hits, no mismatch" % (trials, rays_total * 1e-6, hits * 1e-6))
+    print("OK: %d scenes, %.1f M rays, %.1f M hits, no mismatch; %.1f M (accepted sphere, ancestor box) pairs, no box failed" % (trials, rays_total * 1e-6, hits * 1e-6, pairs * 1e-6))
 
 
 main()
