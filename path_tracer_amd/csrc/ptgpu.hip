@@ -525,7 +525,9 @@ __device__ __forceinline__ void scene_is_hit_tree(const Tree T, uint32_t &cur, u
         if (exit_at != 0u && walking != walking0 && (uint32_t)__popcll(walking) <= exit_at) break;
         w_iters += (unsigned long long)__popcll(walking & (0ull - walking)); // + 1 (the lowest walking lane), in a form that stays a scalar popcount: as `n++` the compiler keeps this wave-uniform count in a VGPR, two VALU instructions per iteration
 #ifdef PT_WALK_PROFILE
+        const unsigned long long m_stalled = __ballot(cur != Tree::kNone && (cur & Tree::kLeafBit)); // at a second leaf while `pend` is taken: waits for the flush
         if ((tid & 63u) == 0u) {
+            atomicAdd(&g_walk_prof[5], (unsigned long long)__popcll(walking)); atomicAdd(&g_walk_prof[6], (unsigned long long)__popcll(m_stalled));
             const bool fl = (uint32_t)__popcll(m_pend) >= flush_at || m_inner == 0ull;
             atomicAdd(&g_walk_prof[0], fl ? (unsigned long long)__popcll(m_pend) : 0ull); atomicAdd(&g_walk_prof[1], (unsigned long long)__popcll(m_inner));
             atomicAdd(&g_walk_prof[2], fl ? 1ull : 0ull); atomicAdd(&g_walk_prof[3], m_inner ? 1ull : 0ull);
@@ -2785,6 +2787,7 @@ static int render_sum_impl(ptgpu_ctx *ctx, const pt_config *cfg, float *d_rgb_su
         if (hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_walk_prof), sizeof wp) == hipSuccess && wp[4]) {
             fprintf(stderr, "[walk profile] loop iterations %llu: with a lane at a leaf %.3f (%.1f lanes each), with a lane at an inner node %.3f (%.1f lanes each)\n", wp[4],
                     (double)wp[2] / wp[4], (double)wp[0] / (wp[2] ? wp[2] : 1), (double)wp[3] / wp[4], (double)wp[1] / (wp[3] ? wp[3] : 1));
+            fprintf(stderr, "[walk profile] lanes still walking per iteration %.1f, of them stalled at a second leaf %.1f\n", (double)wp[5] / wp[4], (double)wp[6] / wp[4]);
             memset(wp, 0, sizeof wp);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), wp, sizeof wp);
         }
